@@ -1,0 +1,95 @@
+"""The CPU restatement (oracle/dartray_oracle.c) against golden vectors produced by the UNMODIFIED
+reference modules (oracle/make_golden.py -> tests/golden/*.npz). Stage by stage, in the order of
+dartray_main (dartray_hub.f90:12-67). This is what pins the oracle."""
+import numpy as np
+import pytest
+
+import oracle_py as op
+from conftest import GOLDEN_CASES, golden_scaspe_check
+
+# u_*, lum_lost, i_obs and the SED agree bit for bit in the build container; scaspe differs at the
+# 1e-16 level (summation order of the HG normalisation). The tolerances below leave room for a
+# different libm on another host.
+RTOL_U = 1e-12
+RTOL_S = 1e-12
+
+
+def relmax(a, b):
+    s = np.abs(b).max()
+    return 0.0 if s == 0 else np.abs(np.asarray(a) - b).max() / s
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_matches_reference(name, golden):
+    z, path = golden(name)
+    hdr = np.frombuffer(z["case_bin"][:64].tobytes(), dtype=np.int32)
+    nsrc, ndir = int(hdr[6]), int(hdr[7])
+    o = op.Oracle(path, nsrc=nsrc, ndir=ndir)
+    assert list(o.npix) == list(z["npix"]) and list(o.npix_hp) == list(z["npix_hp"]) and list(o.kp) == list(z["kp"])
+    assert o.en_lim == pytest.approx(float(z["en_lim"]), rel=1e-15)
+    hosts = np.flatnonzero(o.src_cell >= 0)
+    assert list(hosts) == list(z["src_cell_hosts"]) and list(o.src_cell[hosts]) == list(z["src_cell_ids"])
+    if nsrc:
+        assert np.array_equal(o.p_src_pos[:nsrc], z["p_src_pos"])
+
+    o.rt_loop("precalc_cell"); o.rt_loop("precalc_src")
+    assert relmax(o.u_fest, z["u_fest"]) <= RTOL_U
+    o.rt_loop("dir_cell"); o.rt_loop("dir_src"); o.rt_mpi("dir_src")
+    assert relmax(o.u_final, z["u_final_dir"]) <= RTOL_U
+    assert relmax(o.lum_lost, z["lum_lost_dir"]) <= RTOL_U
+    for il in range(o.L):
+        golden_scaspe_check(z, "scaspe_dir", il, o.scaspe(il), RTOL_S, name)
+    if ndir:
+        o.rt_loop_iobs("i_obs_dir_cell"); o.rt_loop_iobs("i_obs_dir_src")
+        assert relmax(o.i_obs[:ndir], z["i_obs_dir"]) <= RTOL_U
+        assert relmax(o.sed()[:ndir], z["sed_dir"]) <= RTOL_U
+    while not o.scatt_prepare():
+        o.rt_loop("scatt"); o.rt_mpi("scatt")
+    assert o.iterations == int(z["iterations"])
+    assert relmax(o.u_final, z["u_final"]) <= RTOL_U
+    assert relmax(o.lum_lost, z["lum_lost"]) <= RTOL_U
+    for il in range(o.L):
+        golden_scaspe_check(z, "scaspe_tot", il, o.scaspe_tot(il), RTOL_S, name)
+    if ndir:
+        o.iobs_prepare(); o.rt_loop_iobs("i_obs")
+        assert relmax(o.i_obs[:ndir], z["i_obs"]) <= RTOL_U
+        assert relmax(o.sed()[:ndir], z["sed"]) <= RTOL_U
+    o.close()
+
+
+def test_healpix_roundtrip():
+    """ang2pix_nest(pix2ang_nest(p)) == p for every pixel, nside <= 64 (healpix_routines.f90:30,238)."""
+    import ctypes as C
+    L = op.lib()
+    th, ph = C.c_double(), C.c_double()
+    for k in range(0, 7):
+        nside = 1 << k
+        for p in range(12 * nside * nside):
+            L.orc_pix2ang_nest(nside, p, C.byref(th), C.byref(ph))
+            assert L.orc_ang2pix_nest(nside, th.value, ph.value) == p
+
+
+def test_healpix_children_nest_in_parent():
+    """NESTED property used by the ray split/merge: the four children of pixel p are 4p..4p+3 and
+    ang2pix at the coarser nside of a child's centre returns p (ray_list.f90:213-218)."""
+    import ctypes as C
+    L = op.lib()
+    th, ph = C.c_double(), C.c_double()
+    for nside in (2, 4, 8, 16, 32, 64, 128, 1024, 4096):
+        rng = np.random.default_rng(nside)
+        for p in rng.integers(0, 12 * nside * nside, 300):
+            for c in range(4):
+                L.orc_pix2ang_nest(2 * nside, int(4 * p + c), C.byref(th), C.byref(ph))
+                assert L.orc_ang2pix_nest(nside, th.value, ph.value) == p
+
+
+def test_multithread_oracle_close_to_single(golden):
+    """OpenMP over sources with atomic deposits (the cpu_baseline configuration) agrees with the
+    single-threaded run to rounding."""
+    z, path = golden("cube65")
+    a = op.Oracle(path, nsrc=1, ndir=2); a.run_all(31)
+    b = op.Oracle(path, nsrc=1, ndir=2); b.set_parallel(1, 0, 4); b.run_all(31)
+    assert a.iterations == b.iterations
+    assert relmax(b.u_final, a.u_final) < 1e-11
+    assert relmax(b.scaspe_tot(0), a.scaspe_tot(0)) < 1e-11
+    assert a.counters()["intersections"] == b.counters()["intersections"]
