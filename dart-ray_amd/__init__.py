@@ -7,5 +7,7 @@ the Fortran facade in `dart-ray_amd/fortran/`; the Python here is the thin host 
 tests and the benchmark, plus the synthetic-grid generators.
 """
 from . import grids  # noqa: F401
+from . import host  # noqa: F401
+from .host import DartRayGPU, DartRayError  # noqa: F401
 
-__all__ = ["grids"]
+__all__ = ["grids", "host", "DartRayGPU", "DartRayError"]

@@ -1,0 +1,1027 @@
+// dartray_rt.hip — C-ABI library of the MI355X-native DART-Ray ray-cell path (include/dartray_rt.h).
+//
+// Host side: owns the device copies of the grid and field arrays (reference layout, see DESIGN.md
+// section 2), restates the O(N) set-up helpers of rt_prepare on the host (set_en_lim, prepare_p_src,
+// calc_total_luminosity, set_npix_arr, create_scaspe), launches the kernels of rt_kernels.hpp and
+// performs the stage-end reductions of rt_mpi. No CPU fallback exists: every compute entry point
+// needs a gfx950 device.
+#include "../../include/dartray_rt.h"
+#include "rt_kernels.hpp"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// small device kernels for the stage glue
+// ------------------------------------------------------------------------------------------------
+// calc_total_luminosity_sca (rt_routines.f90:698-708): lumcell(il,i) = sum(scaspe(0:npix_hp-1,i)) for leaves;
+// totals per wavelength for the convergence test (:725-732) and tot_rad_en (:675-684)
+__global__ void k_lumcell_sca(const double* __restrict__ scaspe, const int* __restrict__ cchild, double* __restrict__ lumcell,
+                              double* __restrict__ tot, int N, int L, int il, int npix, int nhp, int all_pix)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0.0;
+    if (i < N) {
+        const double* row = scaspe + (unsigned long long)i * npix;
+        int n = all_pix ? npix : nhp;
+        for (int p = 0; p < n; p++) s += row[p];
+        lumcell[(unsigned long long)i * L + il] = (cchild[i] == -1) ? s : 0.0;
+    }
+    // block reduction -> one atomic per wave
+    double v = s;
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(tot, v);
+}
+
+__global__ void k_axpy(double* __restrict__ y, const double* __restrict__ x, unsigned long long n)
+{
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = y[i] + x[i];
+}
+
+// reduce_u_final_arr (io_routines.f90:3743-3757): u_final = max(u_final - u_fest, 0) [all-reduce] + u_fest
+__global__ void k_u_sub_clamp(double* __restrict__ u_final, const double* __restrict__ u_fest, unsigned long long n)
+{
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { double d = u_final[i] - u_fest[i]; u_final[i] = d < 0 ? 0.0 : d; }
+}
+__global__ void k_scale_sub(double* __restrict__ a, const double* __restrict__ b, double f, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = a[i] - f * b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct drt_ctx {
+    int device = 0, ncu = 256;
+    std::string err;
+    // grid (host copies for the O(N) helpers)
+    int N = 0, max_lvl = 0, base[2] = {0, 0};
+    double modelsize = 0;
+    std::vector<int32_t> cchild, lvl, src_cell, cell_src;
+    std::vector<double> ccoord, csize, csize_arr, carea_arr, cvol_arr;
+    std::vector<uint32_t> cpack;
+    drt_params par{};
+    bool have_par = false, have_grid = false, prepared = false, part2 = false;
+    int L = 0, LP = 1;
+    std::vector<double> ksca, gsca;
+    std::vector<int> npix, npix_hp, kp, ik;
+    int nuniq = 0;
+    std::vector<int> kp_unique, npix_unique;
+    int nsrc = 0, ndir = 0;
+    std::vector<double> p_src_pos, p_src_lum, dir_out;
+    std::vector<double> dens_stars_h, lumcell_h, tot_rad_en;
+    double en_lim = 0;
+    int bm_par_cur = 0, iterations = 0, cnflag = 0;
+    // device
+    int *d_cchild = nullptr, *d_lvl = nullptr, *d_src_cell = nullptr, *d_src_list = nullptr;
+    uint32_t* d_cpack = nullptr;
+    double *d_ccoord = nullptr, *d_csize = nullptr, *d_dens = nullptr, *d_u_fest = nullptr, *d_u_final = nullptr, *d_lumcell = nullptr;
+    double *d_p_src_pos = nullptr, *d_p_src_lum = nullptr, *d_dir_out = nullptr, *d_lum_lost = nullptr, *d_lum_lost_prev = nullptr;
+    double *d_i_obs = nullptr, *d_tot = nullptr;
+    std::vector<double*> d_scaspe, d_scaspe_prev, d_scaspe_tot, d_tab;
+    DevProblem* d_prob = nullptr;
+    DevProblem hprob{};
+    char* d_arena = nullptr;
+    size_t arena_bytes = 4ull << 30;
+    int waves = 0, cap = 0, hcap = 0;
+    unsigned long long wave_stride = 0;
+    unsigned long long* d_counters = nullptr;
+    int *d_error = nullptr, *d_task = nullptr;
+    size_t src_list_cap = 0;
+    int* d_dbg = nullptr;
+    int dbg_cap = 0;
+    double* d_ring_tab[14] = {nullptr}, *d_phi0_tab[14] = {nullptr}, *d_phi1_tab[14] = {nullptr};
+    double* d_dir_out_sc = nullptr;
+    int tab_max_level = 0;
+    drt_counters cnt{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // comm (RCCL, loaded lazily)
+    void* rccl = nullptr;
+    void* comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+static int fail(drt_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, DRT_E_HIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+template <class T> static int dev_upload(drt_ctx* c, T** d, const T* h, size_t n)
+{
+    if (*d) { (void)hipFree(*d); *d = nullptr; }
+    HIPCHK(c, hipMalloc((void**)d, (n ? n : 1) * sizeof(T)));
+    if (n && h) HIPCHK(c, hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return DRT_OK;
+}
+template <class T> static int dev_zero(drt_ctx* c, T** d, size_t n)
+{
+    if (*d) { (void)hipFree(*d); *d = nullptr; }
+    HIPCHK(c, hipMalloc((void**)d, (n ? n : 1) * sizeof(T)));
+    HIPCHK(c, hipMemset(*d, 0, (n ? n : 1) * sizeof(T)));
+    return DRT_OK;
+}
+
+static double ipow(double x, int n)  // x**n as a Fortran runtime evaluates it
+{
+    double r = 1.0;
+    while (n > 0) { if (n & 1) r *= x; x *= x; n >>= 1; }
+    return r;
+}
+
+extern "C" int drt_create(drt_ctx** out, int device)
+{
+    if (!out) return DRT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DRT_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DRT_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DRT_E_NODEVICE;  // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return DRT_E_NODEVICE;
+    drt_ctx* c = new drt_ctx();
+    c->device = device;
+    c->ncu = prop.multiProcessorCount;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return DRT_E_HIP; }
+    if (hipMalloc((void**)&c->d_counters, CNT_N * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&c->d_error, sizeof(int)) != hipSuccess || hipMalloc((void**)&c->d_task, sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&c->d_prob, sizeof(DevProblem)) != hipSuccess || hipMalloc((void**)&c->d_tot, DRT_MAXL * sizeof(double)) != hipSuccess) {
+        delete c;
+        return DRT_E_HIP;
+    }
+    (void)hipMemset(c->d_counters, 0, CNT_N * sizeof(unsigned long long));
+    (void)hipMemset(c->d_error, 0, sizeof(int));
+    *out = c;
+    return DRT_OK;
+}
+
+static void free_fields(drt_ctx* c)
+{
+    for (auto p : c->d_scaspe) if (p) (void)hipFree(p);
+    for (auto p : c->d_scaspe_prev) if (p) (void)hipFree(p);
+    for (auto p : c->d_scaspe_tot) if (p) (void)hipFree(p);
+    for (auto p : c->d_tab) if (p) (void)hipFree(p);
+    c->d_scaspe.clear(); c->d_scaspe_prev.clear(); c->d_scaspe_tot.clear(); c->d_tab.clear();
+}
+
+extern "C" int drt_destroy(drt_ctx* c)
+{
+    if (!c) return DRT_E_ARG;
+    (void)hipSetDevice(c->device);
+    free_fields(c);
+    void* ptrs[] = {c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
+                    c->d_u_final, c->d_lumcell, c->d_p_src_pos, c->d_p_src_lum, c->d_dir_out, c->d_lum_lost, c->d_lum_lost_prev,
+                    c->d_i_obs, c->d_tot, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
+    if (c->d_dir_out_sc) (void)hipFree(c->d_dir_out_sc);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    drt_comm_destroy(c);
+    delete c;
+    return DRT_OK;
+}
+
+extern "C" const char* drt_last_error(const drt_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int drt_configure(drt_ctx* c, size_t arena_bytes, int waves)
+{
+    if (!c) return DRT_E_ARG;
+    if (arena_bytes) c->arena_bytes = arena_bytes;
+    if (waves > 0) c->waves = waves;
+    if (c->d_arena) { (void)hipFree(c->d_arena); c->d_arena = nullptr; }
+    return DRT_OK;
+}
+
+// ---- module state in ---------------------------------------------------------------------------------
+extern "C" int drt_set_grid(drt_ctx* c, int32_t N, int32_t max_lvl, const int32_t base[2], const int32_t* cchild,
+                            const int32_t* lvl, const int64_t* cindex, const double* ccoord, const double* csize)
+{
+    if (!c || N < 2 || !base || !cchild || !lvl || !cindex || !ccoord || !csize) return fail(c, DRT_E_ARG, "drt_set_grid: bad argument");
+    if (max_lvl < 1 || max_lvl > DRT_MAXLVL) return fail(c, DRT_E_ARG, "drt_set_grid: max_lvl %d outside 1..%d", max_lvl, DRT_MAXLVL);
+    if (base[0] < 2 || base[0] > 15 || base[1] < 2 || base[1] > 15) return fail(c, DRT_E_ARG, "drt_set_grid: base must be within 2..15");
+    if (cchild[0] != 1) return fail(c, DRT_E_ARG, "drt_set_grid: the root's children must start at index 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->N = N; c->max_lvl = max_lvl; c->base[0] = base[0]; c->base[1] = base[1];
+    c->cchild.assign(cchild, cchild + N);
+    c->lvl.assign(lvl, lvl + N);
+    c->ccoord.assign(ccoord, ccoord + 3ull * N);
+    c->csize.assign(csize, csize + N);
+    c->modelsize = csize[0];  // make_csize_arr (io_routines.f90:677)
+    // set_base (smooth_grid_routines.f90:622-649)
+    long long basediv[2];
+    for (int i = 0; i < 2; i++) { int j = 0; long long b3 = (long long)base[i] * base[i] * base[i]; while (!(b3 < (1ll << j))) j++; basediv[i] = 1ll << j; }
+    double baseinv[2] = {1.0 / (double)base[0], 1.0 / (double)base[1]};
+    // make_csize_arr (io_routines.f90:669-696)
+    c->csize_arr.assign(max_lvl + 1, 0.0); c->carea_arr.assign(max_lvl + 1, 0.0); c->cvol_arr.assign(max_lvl + 1, 0.0);
+    for (int i = 0; i <= max_lvl; i++) {
+        double cs = c->modelsize;
+        if (i > 0) cs = c->modelsize * (baseinv[0] * ipow(baseinv[1], i - 1));
+        c->csize_arr[i] = cs; c->carea_arr[i] = cs * cs; c->cvol_arr[i] = cs * cs * cs;
+    }
+    // cindex_to_ccindd (smooth_grid_routines.f90:793-814) for every cell, packed 4 bits per level
+    c->cpack.assign(3ull * N, 0u);
+    for (int n = 0; n < N; n++) {
+        if (lvl[n] < 0 || lvl[n] > max_lvl) return fail(c, DRT_E_ARG, "drt_set_grid: lvl(%d) = %d out of range", n, lvl[n]);
+        if (cchild[n] != -1 && (cchild[n] < 1 || cchild[n] >= N)) return fail(c, DRT_E_ARG, "drt_set_grid: cchild(%d) = %d out of range", n, cchild[n]);
+        uint32_t w[3] = {0, 0, 0};
+        for (int i = 1; i <= lvl[n]; i++) {
+            long long j;
+            int b = base[(i > 1) ? 1 : 0];
+            if (i > 1) { long long div = basediv[0]; for (int k = 0; k < i - 2; k++) div *= basediv[1]; j = ((cindex[n] / div) & (basediv[1] - 1)) - 1; }
+            else j = (cindex[n] & (basediv[0] - 1)) - 1;
+            if (j < 0) return fail(c, DRT_E_ARG, "drt_set_grid: cindex(%d) has no code at level %d", n, i);
+            int v[3] = {(int)(j % b), (int)((j / b) % b), (int)((j / ((long long)b * b)) % b)};
+            for (int k = 0; k < 3; k++) w[k] |= (uint32_t)v[k] << (4 * (i - 1));
+        }
+        c->cpack[3ull * n] = w[0]; c->cpack[3ull * n + 1] = w[1]; c->cpack[3ull * n + 2] = w[2];
+    }
+    int rc;
+    if ((rc = dev_upload(c, &c->d_cchild, (const int*)cchild, (size_t)N))) return rc;
+    if ((rc = dev_upload(c, &c->d_lvl, (const int*)lvl, (size_t)N))) return rc;
+    if ((rc = dev_upload(c, &c->d_ccoord, ccoord, 3ull * N))) return rc;
+    if ((rc = dev_upload(c, &c->d_csize, csize, (size_t)N))) return rc;
+    if ((rc = dev_upload(c, &c->d_cpack, c->cpack.data(), 3ull * N))) return rc;
+    c->have_grid = true; c->prepared = false; c->part2 = false;
+    return DRT_OK;
+}
+
+extern "C" int drt_set_params(drt_ctx* c, const drt_params* p)
+{
+    if (!c || !p) return fail(c, DRT_E_ARG, "drt_set_params: bad argument");
+    if (p->np_mpi < 1 || p->id_mpi < 0 || p->id_mpi >= p->np_mpi) return fail(c, DRT_E_ARG, "drt_set_params: bad np_mpi/id_mpi");
+    if (p->bm_par <= 0 || p->bm_par_sca <= 0 || p->bm_par_max <= 0) return fail(c, DRT_E_ARG, "drt_set_params: bm_par* must be positive");
+    if (p->kp_sca_max < 0 || p->kp_sca_max > 4) return fail(c, DRT_E_ARG, "drt_set_params: kp_sca_max outside [0,4] (check_input, io_routines.f90:2745)");
+    c->par = *p; c->have_par = true; c->bm_par_cur = p->bm_par; c->prepared = false;
+    return DRT_OK;
+}
+
+extern "C" int drt_set_wavelengths(drt_ctx* c, int32_t lnum, const double* ksca, const double* gsca)
+{
+    if (!c || lnum < 1 || lnum > DRT_MAXL || !ksca || !gsca) return fail(c, DRT_E_ARG, "drt_set_wavelengths: lnum must be within 1..%d", DRT_MAXL);
+    c->L = lnum;
+    c->LP = 1;
+    while (c->LP < lnum) c->LP <<= 1;
+    c->ksca.assign(ksca, ksca + lnum);
+    c->gsca.assign(gsca, gsca + lnum);
+    c->prepared = false;
+    if (c->d_arena) { (void)hipFree(c->d_arena); c->d_arena = nullptr; }
+    return DRT_OK;
+}
+
+extern "C" int drt_set_point_sources(drt_ctx* c, int32_t nsrc, const double* pos, const double* lum)
+{
+    if (!c || nsrc < 0 || (nsrc > 0 && (!pos || !lum))) return fail(c, DRT_E_ARG, "drt_set_point_sources: bad argument");
+    if (c->L < 1) return fail(c, DRT_E_ARG, "drt_set_point_sources: call drt_set_wavelengths first");
+    c->nsrc = nsrc;
+    c->p_src_pos.assign(pos, pos + 3ull * nsrc);
+    c->p_src_lum.assign(lum, lum + (size_t)nsrc * c->L);
+    c->prepared = false;
+    return DRT_OK;
+}
+
+extern "C" int drt_set_observers(drt_ctx* c, int32_t ndir, const double* dir_i_out)
+{
+    if (!c || ndir < 0 || (ndir > 0 && !dir_i_out)) return fail(c, DRT_E_ARG, "drt_set_observers: bad argument");
+    c->ndir = ndir;
+    c->dir_out.assign(dir_i_out, dir_i_out + 2ull * ndir);
+    c->prepared = false;
+    return DRT_OK;
+}
+
+// ---- helpers ------------------------------------------------------------------------------------------
+// set_npix_arr (rt_routines.f90:5235-5315)
+static void set_npix_arr(drt_ctx* c)
+{
+    const double pi = 2 * (double)asinf(1.0f);
+    const int L = c->L;
+    c->npix.assign(L, 0); c->npix_hp.assign(L, 0); c->kp.assign(L, 0); c->ik.assign(L, -1);
+    const double g_th = 2 * (double)1e-3f;
+    for (int i = 0; i < L; i++) {
+        double g = fabs(c->gsca[i]);
+        if (g < g_th) { c->npix_hp[i] = 1; c->kp[i] = -1; continue; }
+        double pmax = (1 - g * g) / pow(1 + g * g - 2 * g, 1.5);
+        double pmin = (1 - g * g) / pow(1 + g * g + 2 * g, 1.5);
+        double cos_hm = (pow(2 * (1 - g * g) / (pmax + pmin), (double)(2.0f / 3.0f)) - (1 + g * g)) / (-2 * g);
+        double fwhm = 2 * acos(cos_hm);
+        double delta_min = fwhm / 5;
+        int k_min = (int)(1 / (2 * (double)log10f(2.0f)) * log10(4 * pi / (12 * delta_min * delta_min)));
+        if (k_min > c->par.kp_sca_max) k_min = c->par.kp_sca_max;
+        c->kp[i] = k_min;
+        c->npix_hp[i] = 12 * (1 << (2 * k_min));
+    }
+    for (int i = 0; i < L; i++) c->npix[i] = c->npix_hp[i] + c->ndir;  // tot_ndir_scaspe = tot_ndir (io_routines.f90:559)
+    c->nuniq = 0; c->kp_unique.clear(); c->npix_unique.clear();
+    for (int k = 0; k <= c->par.kp_sca_max; k++) {
+        bool inc = false;
+        for (int i = 0; i < L; i++) if (c->npix_hp[i] == 12 * (1 << (2 * k))) inc = true;
+        if (!inc) continue;
+        for (int i = 0; i < L; i++) if (c->kp[i] == k) c->ik[i] = c->nuniq;
+        c->kp_unique.push_back(k);
+        c->npix_unique.push_back(12 * (1 << (2 * k)) + c->ndir);
+        c->nuniq++;
+    }
+}
+
+// host pix2ang_nest (healpix_routines.f90:30-136) for the scaspe direction tables (create_scaspe :2827-2848)
+static void h_pix2ang_nest(int nside, int ipix, double* theta, double* phi)
+{
+    static const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
+    static const int jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+    const double halfpi = (double)asinf(1.0f);
+    int npface = nside * nside, nl4 = 4 * nside, face_num = ipix / npface, ipf = ipix % npface;
+    double fn = (double)nside, fact1 = 1.0 / (3.0 * fn * fn), fact2 = 2.0 / (3.0 * fn);
+    int ix = 0, iy = 0;
+    for (int b = 0; b < 15; b++) { ix |= ((ipf >> (2 * b)) & 1) << b; iy |= ((ipf >> (2 * b + 1)) & 1) << b; }
+    int jrt = ix + iy, jpt = ix - iy, jr = jrll[face_num] * nside - jrt - 1, nr, kshift;
+    double z;
+    if (jr < nside) { nr = jr; z = 1.0 - nr * fact1 * nr; kshift = 0; }
+    else if (jr <= 3 * nside) { nr = nside; z = (2 * nside - jr) * fact2; kshift = (jr - nside) & 1; }
+    else { nr = nl4 - jr; z = -1.0 + nr * fact1 * nr; kshift = 0; }
+    *theta = acos(z);
+    int jp = (jpll[face_num] * nr + jpt + 1 + kshift) / 2;
+    if (jp > nl4) jp -= nl4;
+    if (jp < 1) jp += nl4;
+    *phi = (jp - (kshift + 1) * 0.5) * (halfpi / nr);
+}
+
+// Direction tables (DevProblem::ring_tab / phi0_tab / phi1_tab): evaluated with the HOST libm so that
+// pixel-centre sines and cosines are the very numbers the Fortran/CPU path computes
+// (pix2ang_nest, healpix_routines.f90:104-129, then sin/cos in calc_cproj, rt_routines.f90:1945).
+static int build_dir_tables(drt_ctx* c)
+{
+    if (c->tab_max_level > 0 && c->d_ring_tab[c->tab_max_level]) return DRT_OK;
+    int kmax = 10;  // nside 1024
+    if (const char* e = getenv("DRT_TAB_NSIDE")) { int n = atoi(e); kmax = 2; while ((1 << (kmax + 1)) <= n && kmax < 13) kmax++; }
+    const double halfpi = (double)asinf(1.0f);
+    for (int k = 1; k <= kmax; k++) {
+        const long nside = 1l << k, nl4 = 4 * nside;
+        const double fn = (double)nside, fact1 = 1.0 / (3.0 * fn * fn), fact2 = 2.0 / (3.0 * fn);
+        std::vector<double> ring(3ull * nl4, 0.0);
+        for (long jr = 1; jr < nl4; jr++) {
+            double z; long nr;
+            if (jr < nside) { nr = jr; z = 1.0 - nr * fact1 * nr; }
+            else if (jr <= 3 * nside) { nr = nside; z = (2 * nside - jr) * fact2; }
+            else { nr = nl4 - jr; z = -1.0 + nr * fact1 * nr; }
+            double th = acos(z);
+            ring[3 * jr] = th; ring[3 * jr + 1] = sin(th); ring[3 * jr + 2] = cos(th);
+        }
+        std::vector<double> p0(3ull * 2 * nside * (nside + 1)), p1(3ull * nl4);
+        for (long nr = 1; nr <= nside; nr++)
+            for (long jp = 1; jp <= 4 * nr; jp++) {
+                double ph = (jp - (0 + 1) * 0.5) * (halfpi / nr);
+                size_t o = 3ull * (2ull * nr * (nr - 1) + (jp - 1));
+                p0[o] = ph; p0[o + 1] = sin(ph); p0[o + 2] = cos(ph);
+            }
+        for (long jp = 1; jp <= nl4; jp++) {
+            double ph = (jp - (1 + 1) * 0.5) * (halfpi / nside);
+            size_t o = 3ull * (jp - 1);
+            p1[o] = ph; p1[o + 1] = sin(ph); p1[o + 2] = cos(ph);
+        }
+        int rc;
+        if ((rc = dev_upload(c, &c->d_ring_tab[k], ring.data(), ring.size()))) return rc;
+        if ((rc = dev_upload(c, &c->d_phi0_tab[k], p0.data(), p0.size()))) return rc;
+        if ((rc = dev_upload(c, &c->d_phi1_tab[k], p1.data(), p1.size()))) return rc;
+    }
+    c->tab_max_level = kmax;
+    return DRT_OK;
+}
+
+static int upload_problem(drt_ctx* c)
+{
+    DevProblem& P = c->hprob;
+    memset(&P, 0, sizeof P);
+    P.N = c->N; P.max_lvl = c->max_lvl; P.base0 = c->base[0]; P.base1 = c->base[1]; P.L = c->L; P.nsrc = c->nsrc; P.ndir = c->ndir;
+    P.pabs_max = (int)(c->modelsize * 10);  // INTEGER pabs_max (rt_routines.f90:22, io_routines.f90:678)
+    P.bm_par = c->bm_par_cur; P.bm_par_max = c->par.bm_par_max;
+    for (int k = 0; k < 3; k++) P.wall_on[k] = c->par.wall_on[k];
+    for (int k = 0; k < 6; k++) P.wall[k] = c->par.wall_coord[k];
+    P.modelsize = c->modelsize; P.rad_lim_ms = c->par.rad_lim * c->modelsize; P.en_lim = c->en_lim; P.cs = c->par.cs;
+    for (int i = 0; i <= c->max_lvl; i++) { P.csize_arr[i] = c->csize_arr[i]; P.carea_arr[i] = c->carea_arr[i]; P.cvol_arr[i] = c->cvol_arr[i]; }
+    P.halfpi = (double)asinf(1.0f); P.pi = 2 * P.halfpi; P.twopi = 2 * P.pi; P.twothird = (double)(2.0f / 3.0f);
+    P.glepsilon = (double)1.0e-7f; P.tau_thin = (double)1.0e-8f; P.len_eps = (double)1.0e-5f;
+    P.outcube_f = (double)(1.0f + 1.0e-7f); P.merge_tol = (double)0.001f;
+    P.cchild = c->d_cchild; P.lvl = c->d_lvl; P.ccoord = c->d_ccoord; P.csize = c->d_csize; P.cpack = c->d_cpack;
+    P.dens = c->d_dens; P.u_fest = c->d_u_fest; P.u_final = c->d_u_final; P.lumcell = c->d_lumcell;
+    P.p_src_pos = c->d_p_src_pos; P.p_src_lum = c->d_p_src_lum; P.src_cell = c->d_src_cell; P.dir_out = c->d_dir_out;
+    P.lum_lost = c->d_lum_lost; P.i_obs = c->d_i_obs;
+    for (int il = 0; il < c->L; il++) {
+        P.ksca[il] = c->ksca[il]; P.g[il] = c->gsca[il];
+        P.npix[il] = c->npix[il]; P.npix_hp[il] = c->npix_hp[il]; P.kp[il] = c->kp[il];
+        P.scaspe[il] = il < (int)c->d_scaspe.size() ? c->d_scaspe[il] : nullptr;
+        P.scaspe_prev[il] = il < (int)c->d_scaspe_prev.size() ? c->d_scaspe_prev[il] : nullptr;
+        P.scaspe_tot[il] = il < (int)c->d_scaspe_tot.size() ? c->d_scaspe_tot[il] : nullptr;
+        P.tab[il] = (c->ik[il] >= 0 && c->ik[il] < (int)c->d_tab.size()) ? c->d_tab[c->ik[il]] : nullptr;
+    }
+    P.arena = c->d_arena; P.wave_stride = c->wave_stride; P.cap = c->cap; P.hcap = c->hcap;
+    P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task;
+    P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap;
+    for (int k = 0; k < 14; k++) { P.ring_tab[k] = c->d_ring_tab[k]; P.phi0_tab[k] = c->d_phi0_tab[k]; P.phi1_tab[k] = c->d_phi1_tab[k]; }
+    P.tab_max_level = c->tab_max_level;
+    P.dir_out_sc = c->d_dir_out_sc;
+    HIPCHK(c, hipMemcpy(c->d_prob, &P, sizeof P, hipMemcpyHostToDevice));
+    return DRT_OK;
+}
+
+static int ensure_arena(drt_ctx* c)
+{
+    if (c->d_arena) return DRT_OK;
+    if (c->waves <= 0) c->waves = c->ncu * 8;
+    c->waves = (c->waves + 3) / 4 * 4;
+    // per wave: 4 queues of `cap` rays (high A/B, low, staging) + a hash table of >= 2*cap slots
+    // (4 + 16 bytes each) + two int arrays of cap entries
+    const unsigned long long per_ray = 4ull * (28 + 8ull * c->LP) + 4ull * 20 + 8;
+    unsigned long long cap = c->arena_bytes / ((unsigned long long)c->waves * per_ray);
+    if (cap > (1ull << 22)) cap = 1ull << 22;
+    cap = cap / 64 * 64;
+    if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, c->waves);
+    int hcap = 64;
+    while (hcap < 2 * (int)cap) hcap <<= 1;
+    c->cap = (int)cap; c->hcap = hcap;
+    c->wave_stride = 4ull * list_bytes(c->cap, c->LP) + 20ull * hcap + 8ull * c->cap;
+    c->wave_stride = (c->wave_stride + 255) / 256 * 256;
+    HIPCHK(c, hipMalloc((void**)&c->d_arena, c->wave_stride * (unsigned long long)c->waves));
+    return DRT_OK;
+}
+
+static const char* trace_error_text(int e)
+{
+    if (e & ERR_CAPACITY) return "a ray queue outgrew its arena (raise arena_bytes or lower waves with drt_configure)";
+    if (e & ERR_NEG_LENGTH) return "negative ray-cell intersection length (rt_routines.f90:1714)";
+    if (e & ERR_CELL_NOT_FOUND) return "next cell not found (rt_routines.f90:1851)";
+    if (e & ERR_RELOCATE) return "host cell of a re-launched ray not found (rt_routines.f90:2031-2063)";
+    if (e & ERR_NSIDE) return "nside out of range (healpix_routines.f90:54)";
+    if (e & ERR_STEPS) return "step limit reached";
+    if (e & ERR_MERGE) return "inconsistent sibling table while merging low rays";
+    return "unknown device error";
+}
+
+// ---- rt_prepare -------------------------------------------------------------------------------------------
+static int prepare_start(drt_ctx* c)
+{
+    if (!c->have_grid || !c->have_par || c->L < 1) return fail(c, DRT_E_ARG, "rt_prepare(start): grid, params and wavelengths must be set first");
+    if (!c->d_dens || c->dens_stars_h.size() != (size_t)c->N * c->L) return fail(c, DRT_E_ARG, "rt_prepare(start): dens_arr and dens_stars_arr must be set first (drt_set_array)");
+    const int N = c->N, L = c->L;
+    set_npix_arr(c);
+    // set_en_lim (rt_routines.f90:3137-3158)
+    int leaves = 0;
+    for (int i = 0; i < N; i++) leaves += (c->cchild[i] == -1);
+    c->en_lim = c->par.accuracy / ((leaves + c->nsrc) * 0.25);
+    // prepare_p_src + fix_ccoord_p_src (rt_routines.f90:535-601)
+    const double tol_p = (double)1.0e-6f;
+    c->src_cell.assign(N, -1);
+    c->cell_src.assign(c->nsrc > 0 ? c->nsrc : 1, 0);
+    for (int i = 0; i < c->nsrc; i++) {
+        bool found = false;
+        for (int j = 0; j < N && !found; j++) {
+            if (c->cchild[j] != -1) continue;
+            double rel[3], cellsize = c->csize[j];
+            int in = 0;
+            for (int k = 0; k < 3; k++) { rel[k] = c->p_src_pos[3ull * i + k] - c->ccoord[3ull * j + k]; if (fabs(rel[k]) < (1. + tol_p) * cellsize / 2.) in++; }
+            if (in == 3) {
+                c->src_cell[j] = i; c->cell_src[i] = j;
+                for (int k = 0; k < 3; k++) if (fabs(rel[k]) >= cellsize / 2.) {
+                    if (rel[k] > 0) c->p_src_pos[3ull * i + k] -= tol_p * cellsize; else c->p_src_pos[3ull * i + k] += tol_p * cellsize;
+                }
+                found = true;
+            }
+        }
+        if (!found) return fail(c, DRT_E_ARG, "host cell of point source %d not found (prepare_p_src, rt_routines.f90:567)", i);
+    }
+    // calc_total_luminosity (rt_routines.f90:605-660)
+    c->lumcell_h.assign((size_t)N * L, 0.0);
+    for (int i = 0; i < N; i++) {
+        if (c->cchild[i] != -1) continue;
+        double v = c->csize[i] * c->csize[i] * c->csize[i];
+        for (int il = 0; il < L; il++) c->lumcell_h[(size_t)i * L + il] = c->dens_stars_h[(size_t)i * L + il] * v;
+    }
+    c->tot_rad_en.assign(L, 0.0);
+    int rc;
+    if ((rc = dev_upload(c, &c->d_lumcell, c->lumcell_h.data(), (size_t)N * L))) return rc;
+    if ((rc = dev_upload(c, &c->d_src_cell, (const int*)c->src_cell.data(), (size_t)N))) return rc;
+    if ((rc = dev_upload(c, &c->d_p_src_pos, c->p_src_pos.data(), 3ull * c->nsrc))) return rc;
+    if ((rc = dev_upload(c, &c->d_p_src_lum, c->p_src_lum.data(), (size_t)c->nsrc * L))) return rc;
+    if ((rc = dev_upload(c, &c->d_dir_out, c->dir_out.data(), 2ull * c->ndir))) return rc;
+    {
+        std::vector<double> sc(4ull * (c->ndir > 0 ? c->ndir : 1), 0.0);
+        for (int j = 0; j < c->ndir; j++) {
+            double th = c->dir_out[j], ph = c->dir_out[c->ndir + j];
+            sc[4ull * j] = sin(th); sc[4ull * j + 1] = cos(th); sc[4ull * j + 2] = sin(ph); sc[4ull * j + 3] = cos(ph);
+        }
+        if ((rc = dev_upload(c, &c->d_dir_out_sc, sc.data(), sc.size()))) return rc;
+    }
+    if ((rc = build_dir_tables(c))) return rc;
+    if ((rc = dev_zero(c, &c->d_u_fest, (size_t)N * L))) return rc;
+    if ((rc = dev_zero(c, &c->d_u_final, (size_t)N * L))) return rc;
+    if ((rc = dev_zero(c, &c->d_lum_lost, (size_t)L))) return rc;
+    if ((rc = dev_zero(c, &c->d_lum_lost_prev, (size_t)L))) return rc;
+    free_fields(c);
+    c->iterations = 0; c->cnflag = 0; c->bm_par_cur = c->par.bm_par; c->part2 = false;
+    c->prepared = true;
+    if ((rc = ensure_arena(c))) return rc;
+    return upload_problem(c);
+}
+
+// create_scaspe + create_i_obs (rt_routines.f90:2784-2852, 2970-3009)
+static int prepare_part2(drt_ctx* c)
+{
+    if (!c->prepared) return fail(c, DRT_E_ARG, "rt_prepare(prep_part2) before rt_prepare(start)");
+    const int N = c->N, L = c->L;
+    free_fields(c);
+    c->d_scaspe.assign(L, nullptr); c->d_scaspe_prev.assign(L, nullptr); c->d_scaspe_tot.assign(L, nullptr);
+    int rc;
+    for (int il = 0; il < L; il++) if ((rc = dev_zero(c, &c->d_scaspe[il], (size_t)N * c->npix[il]))) return rc;
+    c->d_tab.assign(c->nuniq, nullptr);
+    for (int u = 0; u < c->nuniq; u++) {
+        int n = c->npix_unique[u], nhp = n - c->ndir, nside_sca = 1 << c->kp_unique[u];
+        std::vector<double> t(4ull * n);
+        for (int j = 0; j < n; j++) {
+            double th, ph;
+            if (j < nhp) h_pix2ang_nest(nside_sca, j, &th, &ph);
+            else { th = c->dir_out[j - nhp]; ph = c->dir_out[c->ndir + (j - nhp)]; }
+            t[j] = cos(th); t[n + j] = sin(th); t[2ull * n + j] = cos(ph); t[3ull * n + j] = sin(ph);
+        }
+        if ((rc = dev_upload(c, &c->d_tab[u], t.data(), t.size()))) return rc;
+    }
+    if ((rc = dev_zero(c, &c->d_i_obs, (size_t)(c->ndir > 0 ? c->ndir : 1) * (N + c->nsrc) * L))) return rc;
+    c->part2 = true;
+    return upload_problem(c);
+}
+
+static int lumcell_from(drt_ctx* c, const std::vector<double*>& arr, int all_pix, std::vector<double>& totals)
+{
+    const int N = c->N, L = c->L;
+    HIPCHK(c, hipMemset(c->d_tot, 0, DRT_MAXL * sizeof(double)));
+    for (int il = 0; il < L; il++)
+        hipLaunchKernelGGL(k_lumcell_sca, dim3((N + 255) / 256), dim3(256), 0, 0, arr[il], c->d_cchild, c->d_lumcell, c->d_tot + il, N, L, il,
+                           c->npix[il], c->npix_hp[il], all_pix);
+    totals.assign(L, 0.0);
+    HIPCHK(c, hipMemcpy(totals.data(), c->d_tot, L * sizeof(double), hipMemcpyDeviceToHost));
+    c->lumcell_h.resize((size_t)N * L);
+    HIPCHK(c, hipMemcpy(c->lumcell_h.data(), c->d_lumcell, (size_t)N * L * sizeof(double), hipMemcpyDeviceToHost));
+    return DRT_OK;
+}
+
+// rt_prepare, case rtt_scatt (dartray_hub.f90:432-457) + calc_total_luminosity_sca (rt_routines.f90:663-758)
+static int prepare_scatt(drt_ctx* c)
+{
+    if (!c->part2) return fail(c, DRT_E_ARG, "rt_prepare(scatt) before rt_prepare(prep_part2)");
+    const int N = c->N, L = c->L;
+    const size_t NL = (size_t)N * L;
+    HIPCHK(c, hipMemcpy(c->d_u_fest, c->d_u_final, NL * sizeof(double), hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipMemcpy(c->d_lum_lost_prev, c->d_lum_lost, L * sizeof(double), hipMemcpyDeviceToDevice));
+    c->iterations++;
+    int rc;
+    if (c->iterations == 1) {
+        for (int il = 0; il < L; il++) {
+            size_t n = (size_t)N * c->npix[il];
+            if ((rc = dev_zero(c, &c->d_scaspe_tot[il], n))) return rc;
+            HIPCHK(c, hipMemcpy(c->d_scaspe_tot[il], c->d_scaspe[il], n * sizeof(double), hipMemcpyDeviceToDevice));  // create_scaspe_tot
+            if ((rc = dev_zero(c, &c->d_scaspe_prev[il], n))) return rc;                                             // create_scaspe_prev
+        }
+        c->bm_par_cur = c->par.bm_par_sca;
+    }
+    for (int il = 0; il < L; il++)
+        HIPCHK(c, hipMemcpy(c->d_scaspe_prev[il], c->d_scaspe[il], (size_t)N * c->npix[il] * sizeof(double), hipMemcpyDeviceToDevice));
+    std::vector<double> tot;
+    if ((rc = lumcell_from(c, c->d_scaspe, 0, tot))) return rc;
+    if (c->iterations == 1) c->tot_rad_en = tot;  // parents hold zeros, so the leaf sum equals sum over all cells (:682)
+    double sum_tot = 0;
+    for (int il = 0; il < L; il++) sum_tot += c->tot_rad_en[il];
+    if (sum_tot > 0) {
+        bool all = true;
+        for (int il = 0; il < L; il++) if (!(tot[il] / c->tot_rad_en[il] < c->par.conv_en_lim)) all = false;
+        c->cnflag = all ? 1 : 0;
+    } else c->cnflag = 1;
+    if (c->par.max_sca_iterations >= 0 && c->iterations > c->par.max_sca_iterations) c->cnflag = 1;
+    // sequential scattering bookkeeping (:747-756)
+    for (int il = 0; il < L; il++) {
+        size_t n = (size_t)N * c->npix[il];
+        if (c->iterations > 1) hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, 0, c->d_scaspe_tot[il], c->d_scaspe[il], (unsigned long long)n);
+        HIPCHK(c, hipMemsetAsync(c->d_scaspe[il], 0, n * sizeof(double), 0));
+    }
+    HIPCHK(c, hipDeviceSynchronize());
+    return upload_problem(c);
+}
+
+extern "C" int drt_rt_prepare(drt_ctx* c, int32_t rt_type)
+{
+    if (!c) return DRT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    switch (rt_type) {
+    case DRT_RTT_START: return prepare_start(c);
+    case DRT_RTT_PREP_PART2: return prepare_part2(c);
+    case DRT_RTT_SCATT: return prepare_scatt(c);
+    case DRT_RTT_I_OBS: {  // calc_total_luminosity_sca, case rtt_i_obs (rt_routines.f90:760-771)
+        if (c->d_scaspe_tot.empty() || !c->d_scaspe_tot[0]) return fail(c, DRT_E_ARG, "rt_prepare(i_obs): no scaspe_tot (run the scattering stage first)");
+        std::vector<double> tot;
+        return lumcell_from(c, c->d_scaspe_tot, 1, tot);
+    }
+    default: return fail(c, DRT_E_ARG, "drt_rt_prepare: rt_type %d not handled", rt_type);
+    }
+}
+
+// ---- rt_loop ---------------------------------------------------------------------------------------------
+static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list)
+{
+    const int N = c->N, L = c->L, np = c->par.np_mpi, id = c->par.id_mpi;
+    list.clear();
+    const bool psrc = (rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC || rt_type == DRT_RTT_I_OBS_DIR_SRC);
+    const bool iobs = (rt_type == DRT_RTT_I_OBS_DIR_CELL || rt_type == DRT_RTT_I_OBS_DIR_SRC || rt_type == DRT_RTT_I_OBS);
+    for (int i = 0; i < N; i++) {
+        if (!iobs && (i % np) != id) continue;  // i = im*np_mpi + id_mpi (rt_routines.f90:1005); rt_loop_iobs has no split (:1498)
+        if (c->cchild[i] != -1) continue;
+        double s = 0;
+        if (psrc) { if (c->src_cell[i] != -1) for (int il = 0; il < L; il++) s += c->p_src_lum[(size_t)c->src_cell[i] * L + il]; }
+        else for (int il = 0; il < L; il++) s += c->lumcell_h[(size_t)i * L + il];
+        if (s == 0) continue;  // rt_routines.f90:1016
+        list.push_back(i);
+    }
+    if (list.size() > c->src_list_cap || !c->d_src_list) {
+        if (c->d_src_list) (void)hipFree(c->d_src_list);
+        c->src_list_cap = list.size() + 1024;
+        HIPCHK(c, hipMalloc((void**)&c->d_src_list, c->src_list_cap * sizeof(int)));
+    }
+    if (!list.empty()) HIPCHK(c, hipMemcpy(c->d_src_list, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
+    return DRT_OK;
+}
+
+static int check_device_error(drt_ctx* c)
+{
+    int e = 0;
+    HIPCHK(c, hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(c->d_error, 0, sizeof(int));
+        return fail(c, (e & ERR_CAPACITY) ? DRT_E_CAPACITY : DRT_E_TRACE, "device: %s (flags 0x%x)", trace_error_text(e), e);
+    }
+    return DRT_OK;
+}
+
+static int pull_counters(drt_ctx* c)
+{
+    unsigned long long h[CNT_N];
+    HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    c->cnt.intersections = (int64_t)h[CNT_INTERSECTIONS]; c->cnt.rays = (int64_t)h[CNT_RAYS];
+    c->cnt.deposits = (int64_t)h[CNT_DEPOSITS]; c->cnt.scaspe_adds = (int64_t)h[CNT_SCASPE];
+    return DRT_OK;
+}
+
+template <int LP> static void launch_stage(drt_ctx* c, const StageArgs& a, int blocks)
+{
+    hipLaunchKernelGGL(rt_stage_kernel<LP>, dim3(blocks), dim3(256), 0, 0, c->d_prob, a);
+}
+template <int LP> static void launch_iobs(drt_ctx* c, int rt, int nsrc, int blocks)
+{
+    hipLaunchKernelGGL(rt_iobs_kernel<LP>, dim3(blocks), dim3(256), 0, 0, c->d_prob, rt, c->d_src_list, nsrc);
+}
+
+extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
+{
+    if (!c) return DRT_E_ARG;
+    if (!c->prepared) return fail(c, DRT_E_ARG, "drt_rt_loop before drt_rt_prepare(start)");
+    const bool precalc = (rt_type == DRT_RTT_PRECALC_CELL || rt_type == DRT_RTT_PRECALC_SRC);
+    const bool direct = (rt_type == DRT_RTT_DIR_CELL || rt_type == DRT_RTT_DIR_SRC || rt_type == DRT_RTT_SCATT);
+    if (!precalc && !direct) return fail(c, DRT_E_ARG, "drt_rt_loop: rt_type %d is not a ray-tracing stage", rt_type);
+    if (direct && !c->part2) return fail(c, DRT_E_ARG, "drt_rt_loop(%d) before drt_rt_prepare(prep_part2)", rt_type);
+    if (rt_type == DRT_RTT_SCATT && c->iterations < 1) return fail(c, DRT_E_ARG, "drt_rt_loop(scatt) before drt_rt_prepare(scatt)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    std::vector<int> list;
+    if ((rc = build_src_list(c, rt_type, list))) return rc;
+    c->cnt.sources = (int64_t)list.size();
+    c->cnt.kernel_ms = 0; c->cnt.launches = 0;
+    if (list.empty()) return DRT_OK;
+    if ((rc = ensure_arena(c))) return rc;
+    if (c->hprob.arena != c->d_arena || c->hprob.bm_par != c->bm_par_cur) if ((rc = upload_problem(c))) return rc;
+    StageArgs a;
+    a.rt_type = rt_type; a.nsources = (int)list.size(); a.src_list = c->d_src_list; a.scatter = direct ? 1 : 0;
+    const bool psrc = (rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC);
+    int G = (64 / c->LP) / 4;  // 4 children per sector: one task fills the wave's ray slots on its first step
+    if (G < 1) G = 1;
+    if (G > 16) G = 16;
+    if (psrc) G = 1;  // few, deep sources: one sector per wave
+    a.sectors_per_task = G;
+    long long ntasks = (long long)list.size() * (48 / G);
+    int blocks = (int)((ntasks + 3) / 4);
+    if (blocks > c->waves / 4) blocks = c->waves / 4;
+    HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+    HIPCHK(c, hipEventRecord(c->ev0, 0));
+    switch (c->LP) {
+    case 1: launch_stage<1>(c, a, blocks); break;
+    case 2: launch_stage<2>(c, a, blocks); break;
+    case 4: launch_stage<4>(c, a, blocks); break;
+    case 8: launch_stage<8>(c, a, blocks); break;
+    case 16: launch_stage<16>(c, a, blocks); break;
+    case 32: launch_stage<32>(c, a, blocks); break;
+    default: launch_stage<64>(c, a, blocks); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, 0));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->cnt.kernel_ms = ms; c->cnt.launches = 1;
+    if ((rc = check_device_error(c))) return rc;
+    return pull_counters(c);
+}
+
+extern "C" int drt_rt_loop_iobs(drt_ctx* c, int32_t rt_type)
+{
+    if (!c) return DRT_E_ARG;
+    if (!c->part2) return fail(c, DRT_E_ARG, "drt_rt_loop_iobs before drt_rt_prepare(prep_part2)");
+    if (rt_type != DRT_RTT_I_OBS_DIR_CELL && rt_type != DRT_RTT_I_OBS_DIR_SRC && rt_type != DRT_RTT_I_OBS)
+        return fail(c, DRT_E_ARG, "drt_rt_loop_iobs: rt_type %d is not an i_obs stage", rt_type);
+    if (c->ndir == 0) return DRT_OK;  // no observer (rt_routines.f90:1481)
+    if (c->par.id_mpi != 0) return DRT_OK;  // no_communications: only the main process (rt_routines.f90:1483)
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    std::vector<int> list;
+    if ((rc = build_src_list(c, rt_type, list))) return rc;
+    c->cnt.sources = (int64_t)list.size(); c->cnt.kernel_ms = 0; c->cnt.launches = 0;
+    if (list.empty()) return DRT_OK;
+    long long nrays = (long long)list.size() * c->ndir;
+    int R = 64 / c->LP;
+    int blocks = (int)((nrays + 4ll * R - 1) / (4ll * R));
+    if (blocks > c->ncu * 8) blocks = c->ncu * 8;
+    HIPCHK(c, hipEventRecord(c->ev0, 0));
+    switch (c->LP) {
+    case 1: launch_iobs<1>(c, rt_type, (int)list.size(), blocks); break;
+    case 2: launch_iobs<2>(c, rt_type, (int)list.size(), blocks); break;
+    case 4: launch_iobs<4>(c, rt_type, (int)list.size(), blocks); break;
+    case 8: launch_iobs<8>(c, rt_type, (int)list.size(), blocks); break;
+    case 16: launch_iobs<16>(c, rt_type, (int)list.size(), blocks); break;
+    case 32: launch_iobs<32>(c, rt_type, (int)list.size(), blocks); break;
+    default: launch_iobs<64>(c, rt_type, (int)list.size(), blocks); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, 0));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->cnt.kernel_ms = ms; c->cnt.launches = 1;
+    if ((rc = check_device_error(c))) return rc;
+    return pull_counters(c);
+}
+
+// ---- RCCL, loaded at run time so that the library has no link-time dependency on it ------------------
+struct drt_uid { char b[DRT_UNIQUE_ID_BYTES]; };  // ncclUniqueId is passed by value: 128 bytes
+typedef int (*nccl_get_uid_t)(void*);
+typedef int (*nccl_init_rank_t)(void**, int, drt_uid, int);
+typedef int (*nccl_allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_destroy_t)(void*);
+static void* g_rccl = nullptr;
+static void* rccl_sym(const char* name)
+{
+    if (!g_rccl) {
+        const char* env = getenv("DRT_RCCL_LIB");
+        const char* cand[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* p : cand) { if (!p) continue; g_rccl = dlopen(p, RTLD_NOW | RTLD_GLOBAL); if (g_rccl) break; }
+    }
+    return g_rccl ? dlsym(g_rccl, name) : nullptr;
+}
+
+extern "C" int drt_comm_unique_id(char id[DRT_UNIQUE_ID_BYTES])
+{
+    nccl_get_uid_t f = (nccl_get_uid_t)rccl_sym("ncclGetUniqueId");
+    if (!f) return DRT_E_COMM;
+    return f(id) == 0 ? DRT_OK : DRT_E_COMM;
+}
+
+extern "C" int drt_comm_init(drt_ctx* c, int32_t nranks, int32_t rank, const char id[DRT_UNIQUE_ID_BYTES])
+{
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, DRT_E_ARG, "drt_comm_init: bad argument");
+    c->nranks = nranks; c->rank = rank;
+    if (nranks == 1) return DRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    nccl_init_rank_t f = (nccl_init_rank_t)rccl_sym("ncclCommInitRank");
+    if (!f) return fail(c, DRT_E_COMM, "RCCL library not found (set DRT_RCCL_LIB)");
+    drt_uid u;
+    memcpy(u.b, id, DRT_UNIQUE_ID_BYTES);
+    int r = f(&c->comm, nranks, u, rank);
+    if (r != 0) return fail(c, DRT_E_COMM, "ncclCommInitRank failed (%d)", r);
+    return DRT_OK;
+}
+
+extern "C" int drt_comm_destroy(drt_ctx* c)
+{
+    if (!c) return DRT_E_ARG;
+    if (c->comm) {
+        nccl_destroy_t f = (nccl_destroy_t)rccl_sym("ncclCommDestroy");
+        if (f) f(c->comm);
+        c->comm = nullptr;
+    }
+    return DRT_OK;
+}
+
+static int allreduce_sum(drt_ctx* c, double* d, size_t n)
+{
+    if (c->nranks == 1) return DRT_OK;
+    nccl_allreduce_t f = (nccl_allreduce_t)rccl_sym("ncclAllReduce");
+    if (!f || !c->comm) return fail(c, DRT_E_COMM, "drt_rt_mpi: np_mpi > 1 but no communicator (drt_comm_init)");
+    int r = f(d, d, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, 0);
+    if (r != 0) return fail(c, DRT_E_COMM, "ncclAllReduce failed (%d)", r);
+    return DRT_OK;
+}
+
+// rt_mpi (io_routines.f90:3667-3704)
+extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
+{
+    if (!c || !c->prepared) return fail(c, DRT_E_ARG, "drt_rt_mpi: not prepared");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t NL = (size_t)c->N * c->L;
+    int rc;
+    if (rt_type == DRT_RTT_PRECALC_SRC) {  // reduce_u_fest_arr (:3708-3729)
+        if ((rc = allreduce_sum(c, c->d_u_fest, NL))) return rc;
+    } else if (rt_type == DRT_RTT_DIR_SRC || rt_type == DRT_RTT_SCATT) {
+        // reduce_u_final_arr (:3732-3761)
+        if (rt_type == DRT_RTT_SCATT) hipLaunchKernelGGL(k_u_sub_clamp, dim3(1024), dim3(256), 0, 0, c->d_u_final, c->d_u_fest, (unsigned long long)NL);
+        if ((rc = allreduce_sum(c, c->d_u_final, NL))) return rc;
+        if (rt_type == DRT_RTT_SCATT) hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, 0, c->d_u_final, c->d_u_fest, (unsigned long long)NL);
+        // reduce_scaspe_arr (:3806-3834), one wavelength at a time
+        for (int il = 0; il < c->L; il++) if ((rc = allreduce_sum(c, c->d_scaspe[il], (size_t)c->N * c->npix[il]))) return rc;
+        // reduce_lum_lost (:3837-3855)
+        if (rt_type == DRT_RTT_SCATT && c->nranks > 1)
+            hipLaunchKernelGGL(k_scale_sub, dim3(1), dim3(64), 0, 0, c->d_lum_lost, c->d_lum_lost_prev, (c->nranks - 1.0) / c->nranks, c->L);
+        if ((rc = allreduce_sum(c, c->d_lum_lost, (size_t)c->L))) return rc;
+    } else return fail(c, DRT_E_ARG, "drt_rt_mpi: rt_type %d has no reduction (io_routines.f90:3697)", rt_type);
+    HIPCHK(c, hipDeviceSynchronize());
+    return DRT_OK;
+}
+
+// ---- module state out ---------------------------------------------------------------------------------
+static int field_ptr(drt_ctx* c, int which, int il, double** d, size_t* n)
+{
+    const size_t NL = (size_t)c->N * c->L;
+    *d = nullptr; *n = 0;
+    switch (which) {
+    case DRT_A_U_FEST: *d = c->d_u_fest; *n = NL; break;
+    case DRT_A_U_FINAL: *d = c->d_u_final; *n = NL; break;
+    case DRT_A_LUMCELL: *d = c->d_lumcell; *n = NL; break;
+    case DRT_A_DENS: *d = c->d_dens; *n = NL; break;
+    case DRT_A_LUM_LOST: *d = c->d_lum_lost; *n = (size_t)c->L; break;
+    case DRT_A_I_OBS: *d = c->d_i_obs; *n = (size_t)c->ndir * (c->N + c->nsrc) * c->L; break;
+    case DRT_A_SCASPE: case DRT_A_SCASPE_TOT: case DRT_A_SCASPE_PREV: {
+        if (il < 0 || il >= c->L) return fail(c, DRT_E_ARG, "wavelength index %d out of range", il);
+        auto& v = which == DRT_A_SCASPE ? c->d_scaspe : which == DRT_A_SCASPE_TOT ? c->d_scaspe_tot : c->d_scaspe_prev;
+        if ((int)v.size() > il) *d = v[il];
+        *n = (size_t)c->N * (c->npix.empty() ? 0 : c->npix[il]);
+        break;
+    }
+    default: return fail(c, DRT_E_ARG, "unknown field %d", which);
+    }
+    if (!*d) return fail(c, DRT_E_ARG, "field %d is not allocated at this stage", which);
+    return DRT_OK;
+}
+
+extern "C" int drt_get_array(drt_ctx* c, int32_t which, int32_t il, double* host, size_t count)
+{
+    if (!c || !host) return DRT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (which == DRT_A_TOT_RAD_EN) {
+        if (count != (size_t)c->L || c->tot_rad_en.size() != count) return fail(c, DRT_E_ARG, "tot_rad_en: count mismatch");
+        memcpy(host, c->tot_rad_en.data(), count * sizeof(double));
+        return DRT_OK;
+    }
+    if (which == DRT_A_DENS_STARS) {
+        if (count != c->dens_stars_h.size()) return fail(c, DRT_E_ARG, "dens_stars_arr: count mismatch");
+        memcpy(host, c->dens_stars_h.data(), count * sizeof(double));
+        return DRT_OK;
+    }
+    double* d; size_t n; int rc;
+    if ((rc = field_ptr(c, which, il, &d, &n))) return rc;
+    if (n != count) return fail(c, DRT_E_ARG, "field %d holds %zu elements, caller passed %zu", which, n, count);
+    HIPCHK(c, hipMemcpy(host, d, n * sizeof(double), hipMemcpyDeviceToHost));
+    return DRT_OK;
+}
+
+extern "C" int drt_set_array(drt_ctx* c, int32_t which, int32_t il, const double* host, size_t count)
+{
+    if (!c || !host) return DRT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t NL = (size_t)c->N * c->L;
+    if (which == DRT_A_DENS) {
+        if (!c->have_grid || c->L < 1 || count != NL) return fail(c, DRT_E_ARG, "dens_arr: set grid and wavelengths first; count must be lnum*tot_ncell");
+        int rc = dev_upload(c, &c->d_dens, host, NL);
+        if (rc == DRT_OK && c->prepared) rc = upload_problem(c);
+        return rc;
+    }
+    if (which == DRT_A_DENS_STARS) {
+        if (!c->have_grid || c->L < 1 || count != NL) return fail(c, DRT_E_ARG, "dens_stars_arr: set grid and wavelengths first; count must be lnum*tot_ncell");
+        c->dens_stars_h.assign(host, host + NL);
+        c->prepared = false;
+        return DRT_OK;
+    }
+    double* d; size_t n; int rc;
+    if ((rc = field_ptr(c, which, il, &d, &n))) return rc;
+    if (n != count) return fail(c, DRT_E_ARG, "field %d holds %zu elements, caller passed %zu", which, n, count);
+    HIPCHK(c, hipMemcpy(d, host, n * sizeof(double), hipMemcpyHostToDevice));
+    if (which == DRT_A_LUMCELL) c->lumcell_h.assign(host, host + n);
+    return DRT_OK;
+}
+
+extern "C" int drt_get_npix(const drt_ctx* c, int32_t il, int32_t* npix, int32_t* npix_hp, int32_t* kp)
+{
+    if (!c || il < 0 || il >= c->L || c->npix.empty()) return DRT_E_ARG;
+    if (npix) *npix = c->npix[il];
+    if (npix_hp) *npix_hp = c->npix_hp[il];
+    if (kp) *kp = c->kp[il];
+    return DRT_OK;
+}
+
+extern "C" int drt_get_src_cell(const drt_ctx* c, int32_t* src_cell, double* ccoord_p_src)
+{
+    if (!c || !c->prepared) return DRT_E_ARG;
+    if (src_cell) memcpy(src_cell, c->src_cell.data(), (size_t)c->N * sizeof(int32_t));
+    if (ccoord_p_src && c->nsrc) memcpy(ccoord_p_src, c->p_src_pos.data(), 3ull * c->nsrc * sizeof(double));
+    return DRT_OK;
+}
+
+extern "C" double drt_en_lim(const drt_ctx* c) { return c ? c->en_lim : 0.0; }
+extern "C" int32_t drt_iterations(const drt_ctx* c) { return c ? c->iterations : -1; }
+extern "C" int32_t drt_cnflag(const drt_ctx* c) { return c ? c->cnflag : -1; }
+
+// calc_sed + sum_i_obs (sed_routines.f90:90-146, 211-246), units 'erg/s/Hz/pc^2/sr'; sed(lnum,tot_ndir)
+extern "C" int drt_calc_sed(drt_ctx* c, double* sed)
+{
+    if (!c || !sed || !c->d_i_obs) return fail(c, DRT_E_ARG, "drt_calc_sed: no i_obs array");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int L = c->L, M = c->N + c->nsrc;
+    std::vector<double> io((size_t)c->ndir * M * L);
+    HIPCHK(c, hipMemcpy(io.data(), c->d_i_obs, io.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const double parsec = (double)3.08567758E16f;
+    for (int il = 0; il < L; il++) for (int j = 0; j < c->ndir; j++) {
+        double s = 0, s2 = 0;
+        for (int i = 0; i < c->N; i++) {
+            double v = io[((size_t)j * M + i) * L + il];
+            v = v * pow(10.0, -7); v = v * pow(10.0, 26) / pow(parsec, 2.);
+            double r = c->csize[i] / c->par.dist_obs;
+            s += v * (r * r);
+        }
+        for (int k = 0; k < c->nsrc; k++) {
+            double v = io[((size_t)j * M + c->N + k) * L + il];
+            v = v * pow(10.0, -7); v = v * pow(10.0, 26) / pow(parsec, 2.);
+            double r = c->csize[c->cell_src[k]] / c->par.dist_obs;
+            s2 += v * (r * r);
+        }
+        sed[(size_t)j * L + il] = s + s2;
+    }
+    return DRT_OK;
+}
+
+// Developer aid (not part of the reference's interface): record every ray launch of the following
+// rt_loop calls as (source cell, nside, pixel, cc_old, ray type, start cell).
+extern "C" int drt_debug_trace(drt_ctx* c, int capacity, int* out, int* count)
+{
+    if (!c) return DRT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (out && c->d_dbg) {
+        int n = 0;
+        HIPCHK(c, hipMemcpy(&n, c->d_dbg, sizeof(int), hipMemcpyDeviceToHost));
+        if (count) *count = n;
+        if (n > c->dbg_cap) n = c->dbg_cap;
+        HIPCHK(c, hipMemcpy(out, c->d_dbg + 1, (size_t)n * 6 * sizeof(int), hipMemcpyDeviceToHost));
+        return DRT_OK;
+    }
+    if (c->d_dbg) { (void)hipFree(c->d_dbg); c->d_dbg = nullptr; }
+    c->dbg_cap = capacity;
+    if (capacity > 0) {
+        HIPCHK(c, hipMalloc((void**)&c->d_dbg, (1 + 6ull * capacity) * sizeof(int)));
+        HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(int)));
+    }
+    if (c->prepared) return upload_problem(c);
+    return DRT_OK;
+}
+
+extern "C" int drt_get_counters(const drt_ctx* c, drt_counters* out)
+{
+    if (!c || !out) return DRT_E_ARG;
+    *out = c->cnt;
+    return DRT_OK;
+}
+
+extern "C" int drt_reset_counters(drt_ctx* c)
+{
+    if (!c) return DRT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemset(c->d_counters, 0, CNT_N * sizeof(unsigned long long)));
+    memset(&c->cnt, 0, sizeof c->cnt);
+    return DRT_OK;
+}

@@ -1,0 +1,242 @@
+// rt_device.hpp — device-side building blocks of the ray-cell kernels (gfx950, wave64).
+//
+// Everything here is written for CDNA4 directly: 64-lane ballots / readlane broadcasts, packed
+// tree coordinates in 32-bit words, SoA ray queues in a per-wave HBM arena. Semantics follow the
+// reference's Fortran (file:line cited per function, paths relative to /root/reference); the
+// arithmetic keeps the reference's operation order and single-precision literals so that branch
+// decisions match the oracle. Compile with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DRT_MAXLVL 8   // levels below the root; 4 bits per level per axis in a 32-bit word
+#define DRT_MAXL 64    // wavelengths carried per ray (one lane each)
+
+// rt_type ids (rt_routines.f90:195-217)
+enum { RTT_PRECALC_CELL = 1, RTT_PRECALC_SRC = 2, RTT_DIR_CELL = 5, RTT_I_OBS_DIR_CELL = 6, RTT_DIR_SRC = 7,
+       RTT_I_OBS_DIR_SRC = 8, RTT_SCATT = 10, RTT_I_OBS = 11 };
+// ray types (ray_list.f90:49-59) and status ids (rt_routines.f90:255-264)
+enum { RAY_HIGH = 0, RAY_LOW = 1, RAY_RECO = 2, RAY_GONE = 3 };
+enum { ST_CONT = 0, ST_GO_HIGH = 1, ST_GONE = 2, ST_GO_LOW = 3, ST_OUT = 4 };
+// error bits
+enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64 };
+
+// counters[] slots
+enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_N = 8 };
+
+struct DevProblem {
+    int N, max_lvl, base0, base1, L, nsrc, ndir, pabs_max;
+    int bm_par, bm_par_max, wall_on[3];
+    double wall[6];
+    double modelsize, rad_lim_ms, en_lim, cs;
+    double csize_arr[DRT_MAXLVL + 1], carea_arr[DRT_MAXLVL + 1], cvol_arr[DRT_MAXLVL + 1];
+    // constants with the reference's precision (see oracle/dartray_oracle.c)
+    double halfpi, pi, twopi, twothird, glepsilon, tau_thin, len_eps, outcube_f, merge_tol;
+    // tree (row G of SURVEY.md section 8a)
+    const int* cchild;
+    const int* lvl;
+    const double* ccoord;    // [N][3]
+    const double* csize;     // [N]
+    const uint32_t* cpack;   // [N][3]  tree coordinates, 4 bits per level (from cindex)
+    // fields, wavelength fastest: [N][L]
+    const double* dens;
+    double* u_fest;
+    double* u_final;
+    const double* lumcell;
+    const double* p_src_pos;  // [nsrc][3]
+    const double* p_src_lum;  // [nsrc][L]
+    const int* src_cell;      // [N]
+    const double* dir_out;    // [2][ndir]
+    double* lum_lost;         // [L]
+    double* i_obs;            // [ndir][N+nsrc][L]
+    // per wavelength
+    double ksca[DRT_MAXL], g[DRT_MAXL];
+    int npix[DRT_MAXL], npix_hp[DRT_MAXL], kp[DRT_MAXL];
+    double* scaspe[DRT_MAXL];             // [N][npix]
+    const double* scaspe_prev[DRT_MAXL];
+    const double* scaspe_tot[DRT_MAXL];
+    const double* tab[DRT_MAXL];          // [4][npix]: cos(theta), sin(theta), cos(phi), sin(phi); null if isotropic
+    // per-wave ray-queue arena
+    char* arena;
+    unsigned long long wave_stride;
+    int cap, hcap;
+    unsigned long long* counters;
+    int* error;
+    int* task_counter;
+    // Direction tables built on the HOST with the host libm (see build_dir_tables in dartray_rt.hip):
+    // per HEALPix level k (nside = 2^k) ring table [4*nside][3] = (theta, sin, cos) indexed by ring jr,
+    // and azimuth tables [..][3] = (phi, sin, cos): kshift=0 rows at 2*nr*(nr-1) + jp-1, kshift=1 rows
+    // (equatorial rings only) at jp-1. Pixel centres then carry bit-identical sines and cosines on
+    // host and device, which keeps every geometric branch of the path identical to the CPU result.
+    const double* ring_tab[14];
+    const double* phi0_tab[14];
+    const double* phi1_tab[14];
+    int tab_max_level;         // largest k with tables; finer levels fall back to device sin/cos/acos
+    const double* dir_out_sc;  // [ndir][4] sin(theta), cos(theta), sin(phi), cos(phi) of the observer directions
+    // optional debug trace of ray launches: dbg[0] = count, then records of 6 ints
+    int* dbg;
+    int dbg_cap;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double bcast_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int first_lane_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+__device__ __forceinline__ int wave_or(int v)
+{
+    for (int off = 1; off < 64; off <<= 1) v |= __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HEALPix NESTED, 32-bit (healpix_routines.f90:30-136, 238-348). The reference's 1024-/128-entry
+// lookup tables (mk_pix2xy :145, mk_xy2pix1 :351) are bit (de)interleaves; done here with shifts.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t compact_even_bits(uint32_t v)
+{
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    v = (v | (v >> 8)) & 0x0000FFFFu;
+    return v;
+}
+__device__ __forceinline__ uint32_t spread_bits(uint32_t v)
+{
+    v &= 0x0000FFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__device__ inline void pix2ang_nest(const DevProblem& P, int nside, int ipix, double& theta, double& phi)
+{
+    const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
+    const int jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+    int npface = nside * nside, nl4 = 4 * nside;
+    int face_num = ipix / npface;
+    int ipf = ipix - face_num * npface;
+    double fn = (double)nside;
+    double fact1 = 1.0 / (3.0 * fn * fn);
+    double fact2 = 2.0 / (3.0 * fn);
+    int ix = (int)compact_even_bits((uint32_t)ipf);
+    int iy = (int)compact_even_bits((uint32_t)ipf >> 1);
+    int jrt = ix + iy, jpt = ix - iy;
+    int jr = jrll[face_num] * nside - jrt - 1;
+    int nr, kshift;
+    double z;
+    if (jr < nside) { nr = jr; z = 1.0 - nr * fact1 * nr; kshift = 0; }
+    else if (jr <= 3 * nside) { nr = nside; z = (2 * nside - jr) * fact2; kshift = (jr - nside) & 1; }
+    else { nr = nl4 - jr; z = -1.0 + nr * fact1 * nr; kshift = 0; }
+    theta = acos(z);
+    int jp = (jpll[face_num] * nr + jpt + 1 + kshift) / 2;
+    if (jp > nl4) jp -= nl4;
+    if (jp < 1) jp += nl4;
+    phi = (jp - (kshift + 1) * 0.5) * (P.halfpi / nr);
+}
+
+// Pixel centre with its sines and cosines. Uses the host-built tables when the level has them.
+struct PixDir { double theta, phi, st, ct, sp, cp; };
+__device__ inline void pix2ang_nest_sc(const DevProblem& P, int nside, int ipix, PixDir& o)
+{
+    const int k = 31 - __clz(nside);
+    if (k > P.tab_max_level) {
+        pix2ang_nest(P, nside, ipix, o.theta, o.phi);
+        o.st = sin(o.theta); o.ct = cos(o.theta); o.sp = sin(o.phi); o.cp = cos(o.phi);
+        return;
+    }
+    const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
+    const int jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+    int npface = nside * nside, nl4 = 4 * nside;
+    int face_num = ipix / npface;
+    int ipf = ipix - face_num * npface;
+    int ix = (int)compact_even_bits((uint32_t)ipf);
+    int iy = (int)compact_even_bits((uint32_t)ipf >> 1);
+    int jrt = ix + iy, jpt = ix - iy;
+    int jr = jrll[face_num] * nside - jrt - 1;
+    int nr, kshift;
+    if (jr < nside) { nr = jr; kshift = 0; }
+    else if (jr <= 3 * nside) { nr = nside; kshift = (jr - nside) & 1; }
+    else { nr = nl4 - jr; kshift = 0; }
+    int jp = (jpll[face_num] * nr + jpt + 1 + kshift) / 2;
+    if (jp > nl4) jp -= nl4;
+    if (jp < 1) jp += nl4;
+    const double* rt = P.ring_tab[k] + 3 * jr;
+    o.theta = rt[0]; o.st = rt[1]; o.ct = rt[2];
+    const double* pt = (kshift == 0) ? (P.phi0_tab[k] + 3ull * (2ull * nr * (nr - 1) + (jp - 1))) : (P.phi1_tab[k] + 3ull * (jp - 1));
+    o.phi = pt[0]; o.sp = pt[1]; o.cp = pt[2];
+}
+
+// ang2pix_nest with z = cos(theta) supplied by the caller (healpix_routines.f90:269)
+__device__ inline int ang2pix_nest_z(const DevProblem& P, int nside, double z, double phi);
+
+__device__ inline int ang2pix_nest(const DevProblem& P, int nside, double theta, double phi)
+{
+    return ang2pix_nest_z(P, nside, cos(theta), phi);
+}
+
+__device__ inline int ang2pix_nest_z(const DevProblem& P, int nside, double z, double phi)
+{
+    double za = fabs(z);
+    double m = fmod(phi, P.twopi);
+    if (m < 0) m += P.twopi;
+    double tt = m / P.halfpi;
+    int face_num, ix, iy;
+    if (za <= P.twothird) {
+        int jp = (int)(nside * (0.5 + tt - z * 0.75));
+        int jm = (int)(nside * (0.5 + tt + z * 0.75));
+        int ifp = jp / nside, ifm = jm / nside;
+        if (ifp == ifm) face_num = (ifp & 3) + 4;
+        else if (ifp < ifm) face_num = (ifp & 3);
+        else face_num = (ifm & 3) + 8;
+        ix = jm & (nside - 1);
+        iy = nside - (jp & (nside - 1)) - 1;
+    } else {
+        int ntt = (int)tt;
+        if (ntt >= 4) ntt = 3;
+        double tp = tt - ntt;
+        double tmp = sqrt(3.0 * (1.0 - za));
+        int jp = (int)(nside * tp * tmp);
+        int jm = (int)(nside * (1.0 - tp) * tmp);
+        if (jp > nside - 1) jp = nside - 1;
+        if (jm > nside - 1) jm = nside - 1;
+        if (z >= 0) { face_num = ntt; ix = nside - jm - 1; iy = nside - jp - 1; }
+        else { face_num = ntt + 8; ix = jp; iy = jm; }
+    }
+    int ipf = (int)(spread_bits((uint32_t)ix) | (spread_bits((uint32_t)iy) << 1));
+    return ipf + face_num * nside * nside;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tree coordinates: ccindd(3,max_lvl) packed as one 32-bit word per axis, level j in bits 4(j-1)..
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nib_get(uint32_t w, int j) { return (int)((w >> (4 * (j - 1))) & 15u); }
+__device__ __forceinline__ uint32_t nib_set(uint32_t w, int j, int v)
+{
+    int s = 4 * (j - 1);
+    return (w & ~(15u << s)) | (((uint32_t)v & 15u) << s);
+}
+
+// ccindd_to_cc (smooth_grid_routines.f90:820-852) with a bounds guard: a lookup that would leave
+// the cell arrays reports "not found" (the reference aborts there, rt_routines.f90:1851).
+__device__ inline bool ccindd_to_cc(const DevProblem& P, uint32_t cx, uint32_t cy, uint32_t cz, int& cc, int& clvl)
+{
+    int l = 1;
+    for (int i = 1; i <= P.max_lvl; i++) {
+        int b = (i > 1) ? P.base1 : P.base0;
+        int k = (nib_get(cz, i) * b + nib_get(cy, i)) * b + nib_get(cx, i);
+        l += k;
+        if (l < 1 || l >= P.N) return false;
+        int ch = P.cchild[l];
+        if (ch == -1) { cc = l; clvl = i; return true; }
+        l = ch;
+    }
+    return false;
+}

@@ -381,12 +381,17 @@ def read_case(path: str, name: str = "case") -> Case:
 
 def blob_case(base=(4, 2), max_lvl: int = 3, nlambda: int = 2, tau: float = 1.0,
               albedo=(0.6, 0.5, 0.4), g=(0.55, 0.0, 0.3), ndir: int = 2, balance: bool = True,
-              emissivity: float = 1.0, p_src=((0.3, -0.2, 0.1),), lum: float = 50.0,
+              emissivity: float = 1.0, p_src=((0.31, -0.23, 0.13),), lum: float = 50.0,
               modelsize: float = 8.0, blob_r: float = 2.0, blob_c=(0.5, 0.4, -0.3),
-              walls: bool = False, name: str = "blob", **kw) -> Case:
+              walls: bool = False, name: str = "blob", rad_lim: float = 0.1037, **kw) -> Case:
     """A dense Gaussian blob, refined towards its centre, with diffuse stellar emissivity and point
     sources: exercises every branch of `deposit` (rt_routines.f90:2426-2537), including the
-    go_low / 4-sibling merge path (ray_list.f90:210-296) when rays leave the refined core."""
+    go_low / 4-sibling merge path (ray_list.f90:210-296) when rays leave the refined core.
+
+    Source positions and rad_lim are deliberately "un-round": with a source at z=0.1, a cell face at
+    z=0.5, a HEALPix ring at cos(theta)=0.5 and rad_lim*modelsize=0.8 the precalc test
+    `psel > rad_lim*modelsize` (rt_routines.f90:2430) lands exactly on its threshold and its outcome
+    depends on the last bit of the math library's cos(acos(0.5)), i.e. differs between any two libms."""
     blob_c = np.asarray(blob_c, dtype=np.float64)
 
     def refine(level, ctr, size):
@@ -419,4 +424,86 @@ def blob_case(base=(4, 2), max_lvl: int = 3, nlambda: int = 2, tau: float = 1.0,
         wall_coord[0] = np.array([0.1, 0.9]) * modelsize - modelsize / 2.0
         wall_coord[2] = np.array([0.2, 0.8]) * modelsize - modelsize / 2.0
     return Case(tree=tree, dens=dens, dens_stars=dens_stars, ksca_norm=alb, gsca=gg, p_src_pos=ppos,
-                p_src_lum=plum, dir_out=dir_out, wall_on=wall_on, wall_coord=wall_coord, name=name, **kw)
+                p_src_lum=plum, dir_out=dir_out, wall_on=wall_on, wall_coord=wall_coord, name=name,
+                rad_lim=rad_lim, **kw)
+
+
+# TRUST-I benchmark inputs at the 32 wavelengths <= 80 um of lambda_list_trustI_basic.dat
+# (max_lambda_stars = 80, TRUSTI_GRIDS/input_trustI_tau0.01_LD.in:26). Columns: lambda [um],
+# kext(lambda)/kext(1 um), albedo, g (linear interpolation of DUST_OPACITY/TRUST/
+# ZDA_BARE_GR_S_Effective.dat as read_av_opacities does, sed_routines.f90:1870-1898), and the
+# stellar luminosity [erg/s/Hz] (log-log interpolation of TRUSTI_GRIDS/BB_T10000_L100000.dat as
+# read_planck_table_trustI does, user_routines_trustI.f90:147-156). Data values, not code.
+TRUSTI_TABLE = np.array([
+    [0.1, 1.48628301e+01, 2.52981121e-01, 6.01118286e-01, 4.76832615e+20],
+    [0.1232847, 1.00709124e+01, 3.25539366e-01, 6.40600022e-01, 3.85294469e+21],
+    [0.1519911, 7.70059606e+00, 3.63591507e-01, 6.29863804e-01, 1.86367634e+22],
+    [0.1873817, 7.94580506e+00, 4.10966812e-01, 5.73687408e-01, 5.94661528e+22],
+    [0.231013, 8.88322940e+00, 4.13310438e-01, 5.12659389e-01, 1.35522835e+23],
+    [0.2848036, 5.86727588e+00, 5.06974607e-01, 5.01633103e-01, 2.35545137e+23],
+    [0.3511192, 4.68497404e+00, 5.20719047e-01, 4.97661707e-01, 3.29767403e+23],
+    [0.4328761, 3.72095632e+00, 5.34140383e-01, 4.74774658e-01, 3.89268628e+23],
+    [0.5336699, 2.84719102e+00, 5.44275949e-01, 4.37074093e-01, 4.02310769e+23],
+    [0.6579332, 2.09286437e+00, 5.38148445e-01, 3.87315011e-01, 3.75280092e+23],
+    [0.8111308, 1.47695426e+00, 5.10677160e-01, 3.26241452e-01, 3.23622778e+23],
+    [1, 1.00000000e+00, 4.62392434e-01, 2.56744818e-01, 2.62814005e+23],
+    [1.232847, 6.52910690e-01, 3.95526564e-01, 1.79934337e-01, 2.03844874e+23],
+    [1.519911, 4.18986620e-01, 3.19163076e-01, 1.11819171e-01, 1.52623360e+23],
+    [1.873817, 2.66698116e-01, 2.39483173e-01, 6.73208815e-02, 1.11199553e+23],
+    [2.31013, 1.70983358e-01, 1.64225864e-01, 4.17986483e-02, 7.93224327e+22],
+    [2.848036, 1.12893789e-01, 1.04609117e-01, 2.80629336e-02, 5.56555751e+22],
+    [3.511192, 7.73526699e-02, 6.35725160e-02, 2.03539864e-02, 3.85464952e+22],
+    [4.328761, 5.46361755e-02, 3.74490654e-02, 1.50211806e-02, 2.64245569e+22],
+    [5.336699, 4.02422391e-02, 2.09754844e-02, 1.05937462e-02, 1.79681859e+22],
+    [6.579332, 3.22588818e-02, 1.04977963e-02, 7.13060833e-03, 1.21392724e+22],
+    [8.111308, 6.85582275e-02, 1.85445941e-03, 4.22375202e-03, 8.15904440e+21],
+    [10, 1.69830399e-01, 6.59885530e-04, 2.58846264e-03, 5.46122723e+21],
+    [12.32847, 7.17302125e-02, 6.67741106e-04, 1.84036727e-03, 3.64336360e+21],
+    [15.19911, 4.84080702e-02, 3.31415484e-04, 2.68951938e-04, 2.42411830e+21],
+    [18.73817, 6.81248935e-02, 1.33411280e-04, -2.46638927e-04, 1.60943094e+21],
+    [23.1013, 4.91642129e-02, 9.13372963e-05, -5.98686433e-04, 1.06669851e+21],
+    [28.48036, 4.19282936e-02, 5.03081880e-05, -1.04008515e-03, 7.05992378e+20],
+    [35.11192, 3.34789598e-02, 3.09689191e-05, -1.27201698e-03, 4.66735618e+20],
+    [43.28761, 1.97148319e-02, 2.35483794e-05, -8.91400727e-04, 3.08277586e+20],
+    [53.36699, 1.12982455e-02, 1.75951571e-05, 1.91485524e-04, 2.03467388e+20],
+    [65.79332, 6.75419853e-03, 1.25726332e-05, 1.06116246e-03, 1.34210697e+20],
+])
+
+
+def trusti_case(tau_z: float = 1.0, max_lvl: int = 4, wavelengths=None, base=(10, 2), name: str = "trustI",
+                top_layers: int = 1, **kw) -> Case:
+    """The TRUST-I slab benchmark as the reference sets it up (BASELINE configs 1 and 2):
+    TRUSTI_GRIDS/input_grid_trustI_tau0.01_LD.in (modelsize 10 pc, base 10,2, refinement of the
+    cells touching the slab's top face z = -2), input_trustI_tau0.01_LD.in (kp_sca_max=1,
+    rad_lim=0.1, accuracy=0.1, conv_en_lim=0.01, bm_par=10, bm_par_sca=5, bm_par_max=200, z wall
+    0..0.3, 7 observer directions theta = 0..pi), point source at (0,0,4) with the T=10^4 K black body.
+    `wavelengths`: indices into TRUSTI_TABLE (default: the single 1-um entry for tau_z=0.01-style
+    runs is index 11; pass range(32) for the full list). `top_layers` > 1 also refines the cells
+    below the top layer (used to reach ~10^5 cells)."""
+    if wavelengths is None:
+        wavelengths = [11]
+    tab = TRUSTI_TABLE[list(wavelengths)]
+    modelsize = 10.0
+    z0, z1 = -5.0, -2.0
+
+    def refine(level, ctr, size):
+        top = np.abs(ctr[:, 2] + size / 2.0 - z1) / abs(z1) < 1e-5
+        if top_layers > 1:
+            depth = (z1 - (ctr[:, 2] + size / 2.0)) / size  # 0 for the top layer, 1 for the next ...
+            top = top | ((depth > -0.5) & (depth < top_layers - 0.5) & (ctr[:, 2] > z0) & (ctr[:, 2] < z1))
+        return top
+
+    tree = build_tree(modelsize, base, max_lvl, refine, balance=True)
+    N = tree.ncell
+    inside = (tree.ccoord[:, 2] >= z0) & (tree.ccoord[:, 2] <= z1)
+    dens_ref = np.where(inside, tau_z / (z1 - z0), 0.0)
+    dens = dens_ref[:, None] * tab[None, :, 1]
+    L = tab.shape[0]
+    theta = np.array([0.0, 0.523599, 1.04720, 1.57080, 2.09440, 2.61799, 3.14159])  # dir_out_trustI.dat
+    dir_out = np.stack([theta, np.zeros_like(theta)], axis=1)
+    wall_coord = np.zeros((3, 2))
+    wall_coord[2] = np.array([0.0, 0.3]) * modelsize - modelsize / 2.0
+    return Case(tree=tree, dens=dens, dens_stars=np.zeros((N, L)), ksca_norm=tab[:, 2].copy(), gsca=tab[:, 3].copy(),
+                p_src_pos=np.array([[0.0, 0.0, 4.0]]), p_src_lum=tab[None, :, 4].copy(), dir_out=dir_out,
+                kp_sca_max=1, rad_lim=0.1, accuracy=0.1, conv_en_lim=0.01, bm_par=10, bm_par_sca=5, bm_par_max=200,
+                wall_on=(False, False, True), wall_coord=wall_coord, dist_obs=10e3, name=name, **kw)

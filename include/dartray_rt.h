@@ -1,0 +1,151 @@
+/*
+ * dartray_rt.h — C ABI of the MI355X-native DART-Ray ray-cell hot path (libdartray_rt.so).
+ *
+ * The reference has no FFI for this path: it sits behind three argument-less Fortran module
+ * procedures called from dartray_hub.f90 — rt_loop (dartray_hub.f90:22,24,31,33,49),
+ * rt_loop_iobs (:37,39,55) and rt_mpi (:25,34,50) — plus the set-up helpers of rt_prepare
+ * (:390-457), all communicating through module variables of smooth_grid_routines.f90 and
+ * rt_routines.f90. This header is the boundary a Fortran facade binds with ISO_C_BINDING
+ * (dart-ray_amd/fortran/dartray_gpu.f90): every entry point names the reference
+ * procedure or module state it stands for. Plain pointers and sizes only; all arrays are HOST
+ * arrays in the reference's own (Fortran, column-major) layout and are copied in/out — the library
+ * never frees or reallocates caller memory (SURVEY.md section 8b "Ownership").
+ *
+ * Error convention: every function returns DRT_OK (0) or a negative DRT_E_* code; the facade turns
+ * a non-zero status into `call stop_prc` (smooth_grid_routines.f90:869-892). drt_last_error()
+ * gives the message. There is NO CPU fallback: without a gfx950 device drt_create fails.
+ */
+#ifndef DARTRAY_RT_H
+#define DARTRAY_RT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRT_OK 0
+#define DRT_E_NODEVICE (-1) /* no HIP device / not gfx950 */
+#define DRT_E_ARG (-2)      /* bad argument or call order */
+#define DRT_E_HIP (-3)      /* HIP runtime error */
+#define DRT_E_TRACE (-4)    /* the device path hit one of the reference's abort conditions
+                               (negative length rt_routines.f90:1714, cell not found :1851/:2031) */
+#define DRT_E_CAPACITY (-5) /* a ray queue outgrew its arena (ray_list.f90:310 grows instead) */
+#define DRT_E_COMM (-6)     /* RCCL error */
+
+/* rt_type ids, identical to rt_routines.f90:195-217 */
+#define DRT_RTT_START 0
+#define DRT_RTT_PRECALC_CELL 1
+#define DRT_RTT_PRECALC_SRC 2
+#define DRT_RTT_PREP_PART2 4
+#define DRT_RTT_DIR_CELL 5
+#define DRT_RTT_I_OBS_DIR_CELL 6
+#define DRT_RTT_DIR_SRC 7
+#define DRT_RTT_I_OBS_DIR_SRC 8
+#define DRT_RTT_SCATT 10
+#define DRT_RTT_I_OBS 11
+
+/* Field selectors for drt_get_array / drt_set_array (module arrays of smooth_grid_routines.f90) */
+#define DRT_A_U_FEST 1      /* u_fest_arr(0:lnum-1,0:tot_ncell-1)            :98  */
+#define DRT_A_U_FINAL 2     /* u_final_arr(0:lnum-1,0:tot_ncell-1)           :102 */
+#define DRT_A_SCASPE 3      /* scaspe_arr(il)%a(0:npix-1,0:tot_ncell-1)      :119 */
+#define DRT_A_SCASPE_TOT 4  /* scaspe_tot_arr(il)%a                          :125 */
+#define DRT_A_SCASPE_PREV 5 /* scaspe_prev_arr(il)%a                         :134 */
+#define DRT_A_LUMCELL 6     /* lumcell(0:lnum-1,0:tot_ncell-1)               :188 */
+#define DRT_A_LUM_LOST 7    /* lum_lost(0:lnum-1)             rt_routines.f90:131 */
+#define DRT_A_I_OBS 8       /* i_obs_arr(0:lnum-1,0:tot_ncell+tot_p_src-1,0:tot_ndir-1) :140 */
+#define DRT_A_DENS 9        /* dens_arr(0:lnum-1,0:tot_ncell-1)              :62  */
+#define DRT_A_DENS_STARS 10 /* dens_stars_arr                                :70  */
+#define DRT_A_TOT_RAD_EN 11 /* tot_rad_en(0:lnum-1)           rt_routines.f90:33  */
+
+typedef struct drt_ctx drt_ctx;
+
+/* Scalars of rt_routines.f90 / smooth_grid_routines.f90 that steer the path. */
+typedef struct drt_params {
+    int32_t kp_sca_max;         /* rt_routines.f90:9   */
+    int32_t bm_par;             /* :14 (INTEGER in the reference) */
+    int32_t bm_par_sca;         /* :16 */
+    int32_t bm_par_max;         /* :18 */
+    double rad_lim;             /* :24 */
+    double accuracy;            /* :31 -> en_lim by set_en_lim :3137 */
+    double conv_en_lim;         /* :27 */
+    double cs;                  /* light speed in csize units per s, set_units :5190 */
+    double dist_obs;            /* :476 */
+    int32_t wall_on[3];         /* x_wall_on, y_wall_on, z_wall_on  :497-501 */
+    double wall_coord[6];       /* x/y/z_wall_coord(2) in model units (after set_walls :2600) */
+    int32_t max_sca_iterations; /* smooth_grid_routines.f90:553; < 0 = unlimited */
+    int32_t np_mpi;             /* number of ranks sharing the sources, rt_routines.f90:1003-1005 */
+    int32_t id_mpi;             /* this rank */
+} drt_params;
+
+typedef struct drt_counters {
+    int64_t intersections; /* passes through the main: loop body of ray_tracing, rt_routines.f90:1689 */
+    int64_t rays;          /* calls of ray_tracing */
+    int64_t deposits;      /* intersections with length /= 0 (:1731) */
+    int64_t scaspe_adds;   /* (intersection, wavelength) pairs that issued a scaspe axpy (:2656) */
+    int64_t sources;       /* sources processed by the last rt_loop */
+    double kernel_ms;      /* device time of the ray-tracing kernel(s) of the last rt_loop (hipEvent) */
+    int64_t launches;      /* kernel launches behind kernel_ms */
+} drt_counters;
+
+/* ---- life cycle ------------------------------------------------------------------------------- */
+int drt_create(drt_ctx **out, int device);
+int drt_destroy(drt_ctx *ctx);
+const char *drt_last_error(const drt_ctx *ctx);
+/* arena_bytes: device memory for the per-wave ray queues (0 = default 4 GiB); waves: persistent
+ * wavefronts (0 = default). */
+int drt_configure(drt_ctx *ctx, size_t arena_bytes, int waves);
+
+/* ---- module state in (grid_initialize, dartray_hub.f90:472-499) ----------------------------------- */
+/* read_main_grid (io_routines.f90:297): cchild, lvl (int32), cindex (int64), ccoord(3,N), csize(N) */
+int drt_set_grid(drt_ctx *ctx, int32_t tot_ncell, int32_t max_lvl, const int32_t base[2],
+                 const int32_t *cchild, const int32_t *lvl, const int64_t *cindex,
+                 const double *ccoord, const double *csize);
+int drt_set_params(drt_ctx *ctx, const drt_params *p);
+/* lnum and the per-wavelength opacities ksca_arr_norm, gsca_arr (smooth_grid_routines.f90:220-222) */
+int drt_set_wavelengths(drt_ctx *ctx, int32_t lnum, const double *ksca_arr_norm, const double *gsca_arr);
+/* read_p_src (io_routines.f90:620-666): ccoord_p_src(3,nsrc), lum_p_src_arr(lnum,nsrc) */
+int drt_set_point_sources(drt_ctx *ctx, int32_t tot_p_src, const double *ccoord_p_src, const double *lum_p_src_arr);
+/* read_dir_out (io_routines.f90:520-570): dir_i_out(tot_ndir,2) */
+int drt_set_observers(drt_ctx *ctx, int32_t tot_ndir, const double *dir_i_out);
+
+/* ---- the three entry points + rt_prepare ---------------------------------------------------------- */
+/* rt_prepare (dartray_hub.f90:386-469). rt_type = DRT_RTT_START: set_en_lim, prepare_p_src,
+ * calc_total_luminosity (needs grid, params, wavelengths, dens, dens_stars); DRT_RTT_PREP_PART2:
+ * create_scaspe, create_i_obs; DRT_RTT_SCATT: the scattering-iteration block (:432-457), after
+ * which drt_cnflag() tells whether to stop; DRT_RTT_I_OBS: calc_total_luminosity_sca. */
+int drt_rt_prepare(drt_ctx *ctx, int32_t rt_type);
+/* rt_loop (rt_routines.f90:985): rt_type in {1,2,5,7,10} */
+int drt_rt_loop(drt_ctx *ctx, int32_t rt_type);
+/* rt_loop_iobs (rt_routines.f90:1470): rt_type in {6,8,11} */
+int drt_rt_loop_iobs(drt_ctx *ctx, int32_t rt_type);
+/* rt_mpi (io_routines.f90:3667): stage-end reductions for rt_type in {2,7,10}; all-reduce over the
+ * communicator attached with drt_comm_init (identity + the u_final clamp on one rank) */
+int drt_rt_mpi(drt_ctx *ctx, int32_t rt_type);
+
+/* ---- module state out -------------------------------------------------------------------------------- */
+/* Copy a field to/from the host. il selects the wavelength for the scaspe arrays (ignored
+ * otherwise). count must equal the field's element count. */
+int drt_get_array(drt_ctx *ctx, int32_t which, int32_t il, double *host, size_t count);
+int drt_set_array(drt_ctx *ctx, int32_t which, int32_t il, const double *host, size_t count);
+/* npix_arr, npix_hp_arr, kp_sca_arr of wavelength il (set_npix_arr, rt_routines.f90:5235) */
+int drt_get_npix(const drt_ctx *ctx, int32_t il, int32_t *npix, int32_t *npix_hp, int32_t *kp);
+int drt_get_src_cell(const drt_ctx *ctx, int32_t *src_cell /* [tot_ncell] */, double *ccoord_p_src /* (3,nsrc) or NULL */);
+double drt_en_lim(const drt_ctx *ctx);
+int32_t drt_iterations(const drt_ctx *ctx);
+int32_t drt_cnflag(const drt_ctx *ctx);
+/* calc_sed + sum_i_obs for units 'erg/s/Hz/pc^2/sr' (sed_routines.f90:90-146, 211-246): sed(lnum,tot_ndir) */
+int drt_calc_sed(drt_ctx *ctx, double *sed);
+int drt_get_counters(const drt_ctx *ctx, drt_counters *out);
+int drt_reset_counters(drt_ctx *ctx);
+
+/* ---- multi-GPU (one process per GPU; rt_mpi's MPI_Allreduce becomes ncclAllReduce over xGMI) ---- */
+#define DRT_UNIQUE_ID_BYTES 128
+int drt_comm_unique_id(char id[DRT_UNIQUE_ID_BYTES]);
+int drt_comm_init(drt_ctx *ctx, int32_t nranks, int32_t rank, const char id[DRT_UNIQUE_ID_BYTES]);
+int drt_comm_destroy(drt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

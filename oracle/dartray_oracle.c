@@ -205,6 +205,7 @@ struct orc_ctx {
     int np, id, nthreads;
     orc_counters cnt;
     int error;
+    FILE *trace; /* developer aid: ORC_TRACE=<file> logs every ray launch */
 };
 
 #define CC(c, i, k) ((c)->ccoord[(size_t)(i) * 3 + (k)])
@@ -427,6 +428,7 @@ static void finish_setup(orc_ctx *c)
     }
     c->iterations = 0; c->cnflag = 0;
     c->np = 1; c->id = 0; c->nthreads = 1;
+    c->trace = getenv("ORC_TRACE") ? fopen(getenv("ORC_TRACE"), "w") : NULL;
     c->bm_par0 = c->bm_par;
 }
 
@@ -522,6 +524,7 @@ void orc_destroy(orc_ctx *c)
     free(c->u_fest); free(c->u_final); free(c->lumcell); free(c->lum_lost); free(c->lum_lost_prev);
     free(c->tot_rad_en); free(c->i_obs);
     free2(c->scaspe, c->L); free2(c->scaspe_tot, c->L); free2(c->scaspe_prev, c->L);
+    if (c->trace) fclose(c->trace);
     free(c);
 }
 
@@ -644,6 +647,15 @@ static void extract_ray_list(tstate *t, int nside)
         /* ray_list.f90:211-296: group four siblings falling in the same coarser pixel */
         int *ipix_arr = (int *)malloc(ni * sizeof(int));
         for (int i = 0; i < ni; i++) ipix_arr[i] = orc_ang2pix_nest(nside, t->ext.r[i].theta, t->ext.r[i].phi);
+        if (getenv("ORC_DEBUG_MERGE")) {
+            for (int i = 0; i < ni; i++) for (int j = i + 1; j < ni; j++) {
+                if (ipix_arr[i] != ipix_arr[j]) continue;
+                int pi_ = orc_ang2pix_nest(2 * nside, t->ext.r[i].theta, t->ext.r[i].phi), pj = orc_ang2pix_nest(2 * nside, t->ext.r[j].theta, t->ext.r[j].phi);
+                if (pi_ == pj) fprintf(stderr, "oracle: two extracted rays share pixel %d at nside %d: i=%d (type %d isel %d dpl %.17g prev %.17g cc %d) j=%d (type %d isel %d dpl %.17g prev %.17g cc %d)\n",
+                    pi_, 2 * nside, i, t->ext.r[i].ray_type, t->ext.r[i].isel, t->ext.r[i].dplane, t->ext.r[i].prev, t->ext.r[i].cc_old,
+                    j, t->ext.r[j].ray_type, t->ext.r[j].isel, t->ext.r[j].dplane, t->ext.r[j].prev, t->ext.r[j].cc_old);
+            }
+        }
         for (int i = 0; i < ni; i++) {
             int ic_arr[5] = {-1, -1, -1, -1, -1};
             if (t->ext.r[i].ray_type == RAY_GONE) continue;
@@ -660,6 +672,13 @@ static void extract_ray_list(tstate *t, int nside)
                     (fabs(dplane_ray - dplane_add) / fabs(dplane_ray) < MERGE_TOL)) {
                     icount++;
                     ic_arr[icount] = j;
+                    if (t->ext.r[j].ray_type == RAY_GONE && getenv("ORC_DEBUG_MERGE")) {
+                        fprintf(stderr, "oracle: entry j=%d already gone is collected again by i=%d (nside %d parent pix %d)\n", j, i, nside, ipix);
+                        for (int q = 0; q < ni; q++) if (ipix_arr[q] == ipix)
+                            fprintf(stderr, "   q=%d type %d isel %d dplane %.17g prev %.17g cc_old %d theta %.17g phi %.17g own pix %d\n", q, t->ext.r[q].ray_type,
+                                    t->ext.r[q].isel, t->ext.r[q].dplane, t->ext.r[q].prev, t->ext.r[q].cc_old, t->ext.r[q].theta, t->ext.r[q].phi,
+                                    orc_ang2pix_nest(2 * nside, t->ext.r[q].theta, t->ext.r[q].phi));
+                    }
                 }
                 if (icount == 4) break;
             }
@@ -919,6 +938,7 @@ static void ray_tracing(orc_ctx *c, tstate *t, int nc, double al, double dl, int
     int incvec[3], cc, isel = 0, isel_old, ray_status, flag_beam, cc_new;
     double prev, psel = 0;
     t->cnt.rays++;
+    if (c->trace) fprintf(c->trace, "%d %d %d %d %d\n", nc, t->nside, (ray_type == RAY_RECO) ? orc_ang2pix_nest(t->nside, dl, al) : ipix, cc_old, ray_type);
     /* calc_cproj, rt_routines.f90:1945-1953 */
     cproj[0] = sin(dl) * cos(al);
     cproj[1] = sin(dl) * sin(al);
@@ -948,9 +968,21 @@ static void ray_tracing(orc_ctx *c, tstate *t, int nc, double al, double dl, int
     for (int il = 0; il < L; il++) t->iq_a[il] = (I[il] > 0);
     if (rt == ORC_RTT_DIR_SRC || rt == ORC_RTT_DIR_CELL || rt == ORC_RTT_SCATT) calc_ffn_arr(c, t, al, dl, ipix);
 
+    int dbg = 0;
+    if (getenv("ORC_DEBUG_RAY")) {
+        int dn = 0, dp = 0;
+        sscanf(getenv("ORC_DEBUG_RAY"), "%d:%d", &dn, &dp);
+        dbg = (t->nside == dn && orc_ang2pix_nest(t->nside, dl, al) == dp);
+        if (dbg) fprintf(stderr, "RAY nside %d pix %d type %d nc %d cc_old %d start cc %d clvl %d prev %.17g dir %.17g %.17g %.17g\n", t->nside, dp, ray_type, nc, cc_old, cc, clvl, prev, 1 / cproj[0], 1 / cproj[1], 1 / cproj[2]);
+    }
     for (;;) {
         t->cnt.intersections++;
         calc_psel(c, t, incvec, &psel, &isel, clvl, cc, cproj);
+        if (dbg) {
+            double beam_f = c->carea_arr[c->lvl[cc]] / (psel * psel), beam_i = 4 * PI_ / (12.0 * t->nside * t->nside);
+            fprintf(stderr, "   cc %d lvl %d ccoord %.6f %.6f %.6f psel %.17g isel %d len %.3e flag_beam %d beam_f/bm %.6g beam_f/bmmax %.6g beam_i %.6g I0 %.6g\n", cc, clvl, CC(c, cc, 0), CC(c, cc, 1), CC(c, cc, 2), psel, isel, psel - prev,
+                    flag_beam, beam_f / c->bm_par, beam_f / c->bm_par_max, beam_i, t->ray_intensity[0]);
+        }
         double length = psel - prev;
         if (fabs(length) < LEN_EPS * c->csize_arr[clvl]) length = 0;
         if (length < 0) { fprintf(stderr, "oracle: negative length %g in ray_tracing (cc=%d nc=%d)\n", length, cc, nc); t->error = 1; return; }
@@ -1303,6 +1335,13 @@ void orc_sed(orc_ctx *c, double *sed)
         }
         sed[(size_t)j * L + il] = s + s2;
     }
+}
+
+/* developer aid: (re)direct the ray-launch trace; NULL closes it */
+void orc_trace_open(orc_ctx *c, const char *path)
+{
+    if (c->trace) fclose(c->trace);
+    c->trace = path ? fopen(path, "w") : NULL;
 }
 
 int orc_ncell(const orc_ctx *c) { return c->N; }

@@ -91,6 +91,8 @@ void orc_sed(orc_ctx *c, double *sed);     /* [ndir][L], sum_i_obs (sed_routines
 void orc_get_counters(const orc_ctx *c, orc_counters *out);
 void orc_reset_counters(orc_ctx *c);
 
+void orc_trace_open(orc_ctx *c, const char *path); /* developer aid: log every ray launch */
+
 /* Unit-level entry points for tests. */
 void orc_pix2ang_nest(int nside, int ipix, double *theta, double *phi);
 int orc_ang2pix_nest(int nside, double theta, double phi);

@@ -46,7 +46,7 @@ def cases():
         "blobA": grids.blob_case(base=(4, 2), max_lvl=3, nlambda=2, name="blobA"),
         # 27-ary tree (base 3,3), unbalanced, walls on, two point sources, 3 wavelengths
         "blobB": grids.blob_case(base=(3, 3), max_lvl=3, nlambda=3, balance=False, walls=True, name="blobB",
-                                 p_src=((0.3, -0.2, 0.1), (-2.0, 1.5, 2.5))),
+                                 p_src=((0.31, -0.23, 0.13), (-2.03, 1.52, 2.46))),
         # deeper tree, strongly forward scattering, kp_sca_max=2 (192+2 scaspe slots)
         "blobC": grids.blob_case(base=(4, 2), max_lvl=4, nlambda=1, balance=False, name="blobC", tau=3.0,
                                  g=(0.7,), kp_sca_max=2),

@@ -1,0 +1,96 @@
+"""Parity of the HIP path (through the C ABI) with the oracle on the same inputs, and with the
+golden vectors of the reference itself. Everything here needs a real MI355X."""
+import numpy as np
+import pytest
+
+import oracle_py as op
+from conftest import GOLDEN_CASES, golden_scaspe_check
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (relative to the array maximum). The GPU path differs from the reference by the order
+# of atomic floating-point sums and by <= 2 ulp in device sin/cos/acos/exp; north_star asks for 1e-4
+# on SEDs, we hold the fields to 1e-9.
+RTOL = 1e-9
+
+
+def relmax(a, b):
+    s = np.abs(b).max()
+    return 0.0 if s == 0 else float(np.abs(np.asarray(a) - b).max() / s)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_gpu_matches_reference_golden(name, golden, pkg):
+    z, path = golden(name)
+    case = pkg.grids.read_case(path, name)
+    g = pkg.DartRayGPU(case)
+    g.rt_prepare("start")
+    assert list(g.npix) == list(z["npix"]) and list(g.kp) == list(z["kp"])
+    assert g.en_lim == pytest.approx(float(z["en_lim"]), rel=1e-15)
+    sc, pos = g.src_cell()
+    hosts = np.flatnonzero(sc >= 0)
+    assert list(hosts) == list(z["src_cell_hosts"])
+    g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+    assert relmax(g.u_fest, z["u_fest"]) <= RTOL
+    g.rt_prepare("prep_part2")
+    g.rt_loop("dir_cell"); g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+    assert relmax(g.u_final, z["u_final_dir"]) <= RTOL
+    assert relmax(g.lum_lost, z["lum_lost_dir"]) <= 1e-7
+    for il in range(g.L):
+        golden_scaspe_check(z, "scaspe_dir", il, g.scaspe(il), RTOL, name)
+    if g.ndir:
+        g.rt_loop_iobs("i_obs_dir_cell"); g.rt_loop_iobs("i_obs_dir_src")
+        assert relmax(g.i_obs, z["i_obs_dir"]) <= RTOL
+        assert relmax(g.sed(), z["sed_dir"]) <= RTOL
+    while not g.scatt_prepare():
+        g.rt_loop("scatt"); g.rt_mpi("scatt")
+    assert g.iterations == int(z["iterations"])
+    assert relmax(g.u_final, z["u_final"]) <= RTOL
+    assert relmax(g.lum_lost, z["lum_lost"]) <= 1e-7
+    for il in range(g.L):
+        golden_scaspe_check(z, "scaspe_tot", il, g.scaspe_tot(il), RTOL, name)
+    if g.ndir:
+        g.rt_prepare("i_obs"); g.rt_loop_iobs("i_obs")
+        assert relmax(g.i_obs, z["i_obs"]) <= RTOL
+        assert relmax(g.sed(), z["sed"]) <= 1e-9   # north_star: 1e-4
+    g.close()
+
+
+def test_gpu_counters_match_oracle(golden, pkg):
+    """Intersections / rays / deposits are the reference's own definitions: the GPU
+    path must count exactly what the sequential algorithm does."""
+    z, path = golden("blobA")
+    case = pkg.grids.read_case(path, "blobA")
+    o = op.Oracle(path, nsrc=1, ndir=2)
+    g = pkg.DartRayGPU(case)
+    g.rt_prepare("start")
+    for rt in ("precalc_cell", "precalc_src"):
+        o.reset_counters(); o.rt_loop(rt)
+        g.reset_counters(); g.rt_loop(rt)
+        co, cg = o.counters(), g.counters()
+        assert (cg["intersections"], cg["rays"], cg["deposits"]) == (co["intersections"], co["rays"], co["deposits"]), rt
+    g.rt_mpi("precalc_src")
+    g.rt_prepare("prep_part2")
+    for rt in ("dir_cell", "dir_src"):
+        o.reset_counters(); o.rt_loop(rt)
+        g.reset_counters(); g.rt_loop(rt)
+        co, cg = o.counters(), g.counters()
+        assert (cg["intersections"], cg["rays"], cg["deposits"]) == (co["intersections"], co["rays"], co["deposits"]), rt
+    g.close()
+
+
+def test_energy_budget_slab(pkg):
+    """Known-answer check (SURVEY.md section 8c ii): with albedo 0 nothing is scattered; what the slab
+    absorbs is below the source luminosity and the luminosity written off as lum_lost stays under the
+    1 % the reference warns about (io_routines.f90:2211-2222)."""
+    case = pkg.grids.slab_case(tau_z=0.5, max_lvl=2, albedo=0.0, g=0.0, ndir=1)
+    g = pkg.DartRayGPU(case)
+    g.run_all(3)
+    u = g.u_final[:, 0]
+    vol = case.tree.csize ** 3
+    absorbed = float((u * case.dens[:, 0] * pkg.grids.CS_PC * vol).sum())
+    lost = float(g.lum_lost[0])
+    lum = float(case.p_src_lum[0, 0])
+    assert 0 < absorbed < lum
+    assert lost / lum < 0.01
+    g.close()
