@@ -431,7 +431,7 @@ static int upload_problem(drt_ctx* c)
         P.scaspe_tot[il] = il < (int)c->d_scaspe_tot.size() ? c->d_scaspe_tot[il] : nullptr;
         P.tab[il] = (c->ik[il] >= 0 && c->ik[il] < (int)c->d_tab.size()) ? c->d_tab[c->ik[il]] : nullptr;
     }
-    P.arena = c->d_arena; P.wave_stride = c->wave_stride; P.cap = c->cap; P.hcap = c->hcap;
+    P.arena = c->d_arena;
     P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task;
     P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap;
     for (int k = 0; k < 14; k++) { P.ring_tab[k] = c->d_ring_tab[k]; P.phi0_tab[k] = c->d_phi0_tab[k]; P.phi1_tab[k] = c->d_phi1_tab[k]; }
@@ -443,22 +443,34 @@ static int upload_problem(drt_ctx* c)
 
 static int ensure_arena(drt_ctx* c)
 {
-    if (c->d_arena) return DRT_OK;
     if (c->waves <= 0) c->waves = c->ncu * 8;
     c->waves = (c->waves + 3) / 4 * 4;
-    // per wave: 4 queues of `cap` rays (high A/B, low, staging) + a hash table of >= 2*cap slots
-    // (4 + 16 bytes each) + two int arrays of cap entries
-    const unsigned long long per_ray = 4ull * (28 + 8ull * c->LP) + 4ull * 20 + 8;
-    unsigned long long cap = c->arena_bytes / ((unsigned long long)c->waves * per_ray);
+    if (c->d_arena) return DRT_OK;
+    HIPCHK(c, hipMalloc((void**)&c->d_arena, c->arena_bytes));
+    return DRT_OK;
+}
+
+// Split the arena among the `waves` wavefronts of one launch. Per wave: 4 queues of `cap` rays
+// (high A/B, low, staging), a hash table of >= 2*cap slots (4 + 16 bytes each) and two int arrays.
+static int carve_arena(drt_ctx* c, int waves, StageArgs& a)
+{
+    const unsigned long long per_ray = 4ull * (28 + 8ull * c->LP) + 4ull * 20 + 8 + 16;
+    unsigned long long cap = c->arena_bytes / ((unsigned long long)waves * per_ray);
     if (cap > (1ull << 22)) cap = 1ull << 22;
     cap = cap / 64 * 64;
-    if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, c->waves);
+    if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, waves);
     int hcap = 64;
     while (hcap < 2 * (int)cap) hcap <<= 1;
-    c->cap = (int)cap; c->hcap = hcap;
-    c->wave_stride = 4ull * list_bytes(c->cap, c->LP) + 20ull * hcap + 8ull * c->cap;
-    c->wave_stride = (c->wave_stride + 255) / 256 * 256;
-    HIPCHK(c, hipMalloc((void**)&c->d_arena, c->wave_stride * (unsigned long long)c->waves));
+    for (;;) {
+        unsigned long long stride = 4ull * list_bytes((int)cap, c->LP) + 20ull * hcap + 8ull * cap;
+        stride = (stride + 255) / 256 * 256;
+        if (stride * (unsigned long long)waves <= c->arena_bytes) { a.cap = (int)cap; a.hcap = hcap; a.wave_stride = stride; break; }
+        cap -= 64;
+        if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, waves);
+        hcap = 64;
+        while (hcap < 2 * (int)cap) hcap <<= 1;
+    }
+    c->cap = a.cap; c->hcap = a.hcap; c->wave_stride = a.wave_stride;
     return DRT_OK;
 }
 
@@ -681,6 +693,8 @@ static int pull_counters(drt_ctx* c)
     HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     c->cnt.intersections = (int64_t)h[CNT_INTERSECTIONS]; c->cnt.rays = (int64_t)h[CNT_RAYS];
     c->cnt.deposits = (int64_t)h[CNT_DEPOSITS]; c->cnt.scaspe_adds = (int64_t)h[CNT_SCASPE];
+    c->cnt.lambda_deposits = (int64_t)h[CNT_LAMDEP]; c->cnt.u_adds = (int64_t)h[CNT_UADD];
+    c->cnt.u_reads = (int64_t)h[CNT_UREAD]; c->cnt.scaspe_slots = (int64_t)h[CNT_SCASLOTS];
     return DRT_OK;
 }
 
@@ -722,6 +736,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     long long ntasks = (long long)list.size() * (48 / G);
     int blocks = (int)((ntasks + 3) / 4);
     if (blocks > c->waves / 4) blocks = c->waves / 4;
+    if ((rc = carve_arena(c, blocks * 4, a))) return rc;
     HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
     HIPCHK(c, hipEventRecord(c->ev0, 0));
     switch (c->LP) {
@@ -877,6 +892,7 @@ static int field_ptr(drt_ctx* c, int which, int il, double** d, size_t* n)
     case DRT_A_LUMCELL: *d = c->d_lumcell; *n = NL; break;
     case DRT_A_DENS: *d = c->d_dens; *n = NL; break;
     case DRT_A_LUM_LOST: *d = c->d_lum_lost; *n = (size_t)c->L; break;
+    case DRT_A_LUM_LOST_PREV: *d = c->d_lum_lost_prev; *n = (size_t)c->L; break;
     case DRT_A_I_OBS: *d = c->d_i_obs; *n = (size_t)c->ndir * (c->N + c->nsrc) * c->L; break;
     case DRT_A_SCASPE: case DRT_A_SCASPE_TOT: case DRT_A_SCASPE_PREV: {
         if (il < 0 || il >= c->L) return fail(c, DRT_E_ARG, "wavelength index %d out of range", il);
@@ -934,6 +950,15 @@ extern "C" int drt_set_array(drt_ctx* c, int32_t which, int32_t il, const double
     if (n != count) return fail(c, DRT_E_ARG, "field %d holds %zu elements, caller passed %zu", which, n, count);
     HIPCHK(c, hipMemcpy(d, host, n * sizeof(double), hipMemcpyHostToDevice));
     if (which == DRT_A_LUMCELL) c->lumcell_h.assign(host, host + n);
+    return DRT_OK;
+}
+
+extern "C" int drt_device_ptr(drt_ctx* c, int32_t which, int32_t il, void** dev_ptr, size_t* count)
+{
+    if (!c || !dev_ptr || !count) return DRT_E_ARG;
+    double* d; size_t n; int rc;
+    if ((rc = field_ptr(c, which, il, &d, &n))) return rc;
+    *dev_ptr = d; *count = n;
     return DRT_OK;
 }
 

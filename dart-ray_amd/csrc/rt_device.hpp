@@ -22,7 +22,7 @@ enum { ST_CONT = 0, ST_GO_HIGH = 1, ST_GONE = 2, ST_GO_LOW = 3, ST_OUT = 4 };
 enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64 };
 
 // counters[] slots
-enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_N = 8 };
+enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7, CNT_N = 8 };
 
 struct DevProblem {
     int N, max_lvl, base0, base1, L, nsrc, ndir, pabs_max;
@@ -58,8 +58,6 @@ struct DevProblem {
     const double* tab[DRT_MAXL];          // [4][npix]: cos(theta), sin(theta), cos(phi), sin(phi); null if isotropic
     // per-wave ray-queue arena
     char* arena;
-    unsigned long long wave_stride;
-    int cap, hcap;
     unsigned long long* counters;
     int* error;
     int* task_counter;

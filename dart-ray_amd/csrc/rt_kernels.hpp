@@ -19,6 +19,9 @@ struct StageArgs {
     const int* src_list;   // cell ids
     int sectors_per_task;  // G: 48 / G tasks per source
     int scatter;           // 1 for dir/scatt stages (scaspe deposits), 0 for precalc
+    // per-launch carve-up of the ray-queue arena: the fewer waves a stage uses, the deeper its queues
+    int cap, hcap;
+    unsigned long long wave_stride;
 };
 
 struct ListView {
@@ -74,7 +77,7 @@ struct Ray {
     double cd, sd, ca, sa;    // cos/sin of the direction used by calc_ads_arr
 };
 
-struct WaveCounters { unsigned long long inter, rays, deps, sca; };
+struct WaveCounters { unsigned long long inter, rays, deps, sca, lamdep, uadd, uread, slots; };
 
 // calc_psel (rt_routines.f90:2307-2351)
 __device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S, Ray& r, double& psel, int& isel)
@@ -204,13 +207,14 @@ __device__ __forceinline__ bool wall_hit(const DevProblem& P, int rt, int cc)
 // r.I / lum_lost. `live` = lane holds a real wavelength of a busy ray.
 __device__ __forceinline__ int deposit(const DevProblem& P, int rt, const SrcInfo& S, Ray& r, bool live, int il, int level,
                                        double length, double psel, unsigned long long grp, double& en_sca,
-                                       double& lum_lost_acc)
+                                       double& lum_lost_acc, WaveCounters& wc)
 {
     en_sca = 0.0;
     const int cc = r.cc, nc = S.nc;
     const bool act = live && r.lam_active;
     const unsigned long long idx = (unsigned long long)cc * P.L + il;
     double dens = act ? P.dens[idx] : 0.0;
+    if (act) wc.lamdep++;
     double tau_c = dens * length;
     double ex = exp(-tau_c);
     int npix_beam = 12 * (level * level);
@@ -238,13 +242,14 @@ __device__ __forceinline__ int deposit(const DevProblem& P, int rt, const SrcInf
         if ((beam_f / P.bm_par_max < beam_i) || (level <= 8) || r.flag_beam) {
             if (act) {
                 double v = i_av * length / P.cs / vol_f * S.area_i * beam_i;
-                if (v != 0.0) atomicAdd(&P.u_fest[idx], v);
+                if (v != 0.0) { atomicAdd(&P.u_fest[idx], v); wc.uadd++; }
             }
         } else return ST_GO_LOW;
     } else {
         if ((beam_f / P.bm_par <= beam_i) && !r.flag_beam) {
             if (act) {
                 double u_beam = i_av * csize_f / P.cs / vol_f * S.area_i * beam_f;
+                wc.uread++;
                 if (u_beam < P.en_lim * P.u_fest[idx]) {
                     I = 0;
                     lum_lost_acc = lum_lost_acc + i_av * beam_i * S.csize_i * S.csize_i;
@@ -258,7 +263,7 @@ __device__ __forceinline__ int deposit(const DevProblem& P, int rt, const SrcInf
         } else if ((beam_f / P.bm_par_max < beam_i) || (level <= 8) || r.flag_beam) {
             if (act) {
                 double v = i_av * length / P.cs / vol_f * S.area_i * beam_i;
-                if (v != 0.0) atomicAdd(&P.u_final[idx], v);
+                if (v != 0.0) { atomicAdd(&P.u_final[idx], v); wc.uadd++; }
                 double k = P.ksca[il];
                 if (cc != nc) {
                     if (tau_c > P.tau_thin) en_sca = I * (1.0 - ex) * k * S.area_i * beam_i;
@@ -295,6 +300,7 @@ __device__ __forceinline__ void flush_scaspe(const DevProblem& P, const Ray& r, 
         const int cc_b = bcast_i(r.cc, src);
         const double e_b = bcast_d(e, src);
         const int np = P.npix[il_b];
+        wc.slots += (unsigned long long)np;
         const double* tab = P.tab[il_b];
         double* dst = P.scaspe[il_b] + (unsigned long long)cc_b * np;
         if (tab) {
@@ -355,8 +361,8 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
     r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.cd = r.sd = r.ca = r.sa = 0;
     long long guard = 0;
 
-    for (int chunk_base = 0; chunk_base < n_items; chunk_base += P.cap) {
-        const int chunk_end = min(n_items, chunk_base + P.cap);
+    for (int chunk_base = 0; chunk_base < n_items; chunk_base += a.cap) {
+        const int chunk_end = min(n_items, chunk_base + a.cap);
         for (int i = lane; i < chunk_end - chunk_base; i += 64) ostat[i] = 0;
         wave_fence();
         int next_item = chunk_base;
@@ -476,7 +482,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                 if (r.cc != S.nc && r.cc != r.cc_new) r.flag_beam = false;
                 if (length != 0. && status == ST_CONT) {
                     if (leader) wc.deps++;
-                    status = deposit(P, rt, S, r, lam_ok, il, level, length, psel, grp, en_sca, lum_lost_acc);
+                    status = deposit(P, rt, S, r, lam_ok, il, level, length, psel, grp, en_sca, lum_lost_acc, wc);
                 }
             }
             if (a.scatter) flush_scaspe<LP>(P, r, en_sca, wc);
@@ -522,7 +528,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
             if (!(bh | bl)) continue;
             const int pos = (st == 1) ? nH + __popcll(bh & lanemask_lt()) : nL + __popcll(bl & lanemask_lt());
             if (st != 0) {
-                if (pos < P.cap) {
+                if (pos < a.cap) {
                     const ListView& o = (st == 1) ? outH : outL;
                     o.ipix[pos] = stg.ipix[i]; o.meta[pos] = stg.meta[i]; o.cc[pos] = stg.cc[i];
                     o.prev[pos] = stg.prev[i]; o.dpl[pos] = stg.dpl[i];
@@ -550,7 +556,7 @@ __device__ __forceinline__ bool sib_match(double d_i, int isel_i, double d_j, in
 }
 
 template <int LP>
-__device__ void extract_low(const DevProblem& P, const ListView low, int& nL, const ListView ext, int& nE,
+__device__ void extract_low(const DevProblem& P, const StageArgs& a, const ListView low, int& nL, const ListView ext, int& nE,
                             const ListView high, int& nH, int* hkey, int* hmem, int* __restrict__ wts, int level, int& err)
 {
     const int lane = lane_id();
@@ -583,7 +589,7 @@ __device__ void extract_low(const DevProblem& P, const ListView low, int& nL, co
     // hash table sized to the next power of two >= 2*nE
     int hsize = 64;
     while (hsize < 2 * nE) hsize <<= 1;
-    if (hsize > P.hcap) { err |= ERR_CAPACITY; nE = 0; return; }
+    if (hsize > a.hcap) { err |= ERR_CAPACITY; nE = 0; return; }
     const int hmask = hsize - 1;
     for (int h = lane; h < hsize; h += 64) { hkey[h] = -1; hmem[4 * h] = -1; hmem[4 * h + 1] = -1; hmem[4 * h + 2] = -1; hmem[4 * h + 3] = -1; }
     wave_fence();
@@ -675,7 +681,7 @@ __device__ void extract_low(const DevProblem& P, const ListView low, int& nL, co
             const int ip = (int)ext.ipix[i];
             if (!mrg) {
                 const int pos = wts[lead] + rank;
-                if (pos < P.cap) {
+                if (pos < a.cap) {
                     high.ipix[pos] = (uint32_t)ip;
                     high.meta[pos] = META(nsl, META_ISEL(m), RAY_RECO, 0);
                     high.cc[pos] = ext.cc[i];
@@ -734,7 +740,7 @@ __device__ void extract_low(const DevProblem& P, const ListView low, int& nL, co
         }
     }
     nH = nH_new;
-    if (nH > P.cap) { err |= ERR_CAPACITY; nH = P.cap; }
+    if (nH > a.cap) { err |= ERR_CAPACITY; nH = a.cap; }
     wave_fence();
 }
 
@@ -749,16 +755,16 @@ __global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restr
     const int il = lane % LP;
     const int waves_per_block = blockDim.x >> 6;
     const int gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
-    char* abase = P.arena + (unsigned long long)gwave * P.wave_stride;
-    const unsigned long long lbytes = list_bytes(P.cap, LP);
+    char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
+    const unsigned long long lbytes = list_bytes(a.cap, LP);
     int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]
-    int* hmem = hkey + P.hcap;                  // [4*hcap] sibling slots + [cap] per-entry codes
-    int* ostat = hmem + 4ull * P.hcap + P.cap;  // [cap] status of parked rays / prefix weights
+    int* hmem = hkey + a.hcap;                  // [4*hcap] sibling slots + [cap] per-entry codes
+    int* ostat = hmem + 4ull * a.hcap + a.cap;  // [cap] status of parked rays / prefix weights
     const int G = a.sectors_per_task;
     const int tasks_per_src = 48 / G;
     const int ntasks = a.nsources * tasks_per_src;
     const int rt = a.rt_type;
-    WaveCounters wc = {0, 0, 0, 0};
+    WaveCounters wc = {0, 0, 0, 0, 0, 0, 0, 0};
     int err = 0;
 
     for (;;) {
@@ -784,10 +790,10 @@ __global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restr
         S.px = P.cpack[3ull * nc]; S.py = P.cpack[3ull * nc + 1]; S.pz = P.cpack[3ull * nc + 2];
 
         // create_high_ray_list (ray_list.f90:71-106) for the G sectors of this task
-        ListView Hc = list_view(abase, lbytes, P.cap, LP, 0);
-        ListView Hn = list_view(abase, lbytes, P.cap, LP, 1);
-        const ListView LW = list_view(abase, lbytes, P.cap, LP, 2);
-        const ListView ST = list_view(abase, lbytes, P.cap, LP, 3);
+        ListView Hc = list_view(abase, lbytes, a.cap, LP, 0);
+        ListView Hn = list_view(abase, lbytes, a.cap, LP, 1);
+        const ListView LW = list_view(abase, lbytes, a.cap, LP, 2);
+        const ListView ST = list_view(abase, lbytes, a.cap, LP, 3);
         double src_lum = 0.0;
         if (il < P.L) {
             if (rt == RTT_PRECALC_SRC || rt == RTT_DIR_SRC) src_lum = P.p_src_lum[(unsigned long long)P.src_cell[nc] * P.L + il];
@@ -815,7 +821,7 @@ __global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restr
                 nH = nHn;
             } else if (nL > 0) {
                 int nE = 0;
-                extract_low<LP>(P, LW, nL, Hn, nE, Hc, nH, hkey, hmem, ostat, level, err);
+                extract_low<LP>(P, a, LW, nL, Hn, nE, Hc, nH, hkey, hmem, ostat, level, err);
                 wave_fence();
                 if (nE > 0) trace_items<LP>(P, a, S, 1, Hn, nE, Hc, nH, LW, nL, ST, ostat, level, lum_lost_acc, wc, err);
                 wave_fence();
@@ -838,15 +844,20 @@ __global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restr
         if (err) break;
     }
     // counters: one atomic per wave
-    unsigned long long ci = wc.inter, cr = wc.rays, cd = wc.deps;
+    unsigned long long ci = wc.inter, cr = wc.rays, cd = wc.deps, cl = wc.lamdep, cu = wc.uadd, cur = wc.uread;
     for (int off = 1; off < 64; off <<= 1) {
         ci += __shfl_xor(ci, off, 64); cr += __shfl_xor(cr, off, 64); cd += __shfl_xor(cd, off, 64);
+        cl += __shfl_xor(cl, off, 64); cu += __shfl_xor(cu, off, 64); cur += __shfl_xor(cur, off, 64);
     }
     if (lane == 0) {
         atomicAdd(&P.counters[CNT_INTERSECTIONS], ci);
         atomicAdd(&P.counters[CNT_RAYS], cr);
         atomicAdd(&P.counters[CNT_DEPOSITS], cd);
         atomicAdd(&P.counters[CNT_SCASPE], wc.sca);
+        atomicAdd(&P.counters[CNT_LAMDEP], cl);
+        atomicAdd(&P.counters[CNT_UADD], cu);
+        atomicAdd(&P.counters[CNT_UREAD], cur);
+        atomicAdd(&P.counters[CNT_SCASLOTS], wc.slots);
         if (err) atomicOr(P.error, err);
     }
 }

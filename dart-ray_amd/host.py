@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(CSRC, "libdartray_rt.so")
 RTT = dict(start=0, precalc_cell=1, precalc_src=2, prep_part2=4, dir_cell=5, i_obs_dir_cell=6, dir_src=7,
            i_obs_dir_src=8, scatt=10, i_obs=11)
 A = dict(u_fest=1, u_final=2, scaspe=3, scaspe_tot=4, scaspe_prev=5, lumcell=6, lum_lost=7, i_obs=8, dens=9,
-         dens_stars=10, tot_rad_en=11)
+         dens_stars=10, tot_rad_en=11, lum_lost_prev=12)
 UNIQUE_ID_BYTES = 128
 
 
@@ -37,13 +37,14 @@ class Params(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("intersections", C.c_int64), ("rays", C.c_int64), ("deposits", C.c_int64), ("scaspe_adds", C.c_int64),
+                ("lambda_deposits", C.c_int64), ("u_adds", C.c_int64), ("u_reads", C.c_int64), ("scaspe_slots", C.c_int64),
                 ("sources", C.c_int64), ("kernel_ms", C.c_double), ("launches", C.c_int64)]
 
 
 EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_set_grid", "drt_set_params",
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
-           "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
+           "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
            "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy"]
 
 
@@ -81,6 +82,7 @@ def lib():
             getattr(L, fn).argtypes = [vp, i32]
         L.drt_get_array.argtypes = [vp, i32, i32, dp, C.c_size_t]
         L.drt_set_array.argtypes = [vp, i32, i32, dp, C.c_size_t]
+        L.drt_device_ptr.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.drt_get_npix.argtypes = [vp, i32, ip, ip, ip]
         L.drt_get_src_cell.argtypes = [vp, ip, dp]
         L.drt_en_lim.argtypes = [vp]
@@ -148,6 +150,10 @@ class DartRayGPU:
         self.set_array("dens", np.ascontiguousarray(case.dens, dtype=np.float64))
         self.set_array("dens_stars", np.ascontiguousarray(case.dens_stars, dtype=np.float64))
         self.npix = self.npix_hp = self.kp = None
+        self.device = device
+        self.np_mpi, self.id_mpi = np_mpi, id_mpi
+        self.group = None       # torch.distributed process group for rt_mpi when np_mpi > 1
+        self.use_dist = False
 
     # ---- plumbing
     def _chk(self, rc):
@@ -178,7 +184,33 @@ class DartRayGPU:
 
     def rt_loop(self, rt): self._chk(self.L_.drt_rt_loop(self.h, RTT[rt] if isinstance(rt, str) else rt))
     def rt_loop_iobs(self, rt): self._chk(self.L_.drt_rt_loop_iobs(self.h, RTT[rt] if isinstance(rt, str) else rt))
-    def rt_mpi(self, rt): self._chk(self.L_.drt_rt_mpi(self.h, RTT[rt] if isinstance(rt, str) else rt))
+    def rt_mpi(self, rt):
+        """rt_mpi (io_routines.f90:3667). One rank: the library's own kernels. Several ranks attached with
+        attach_process_group(): torch.distributed all-reduces (RCCL) straight on the device buffers."""
+        rt = RTT[rt] if isinstance(rt, str) else rt
+        if not self.use_dist:
+            self._chk(self.L_.drt_rt_mpi(self.h, rt))
+            return
+        from . import parallel
+        fields = {"u_fest": self.device_tensor("u_fest"), "u_final": self.device_tensor("u_final")}
+        if rt != RTT["precalc_src"]:
+            fields["lum_lost"] = self.device_tensor("lum_lost")
+            fields["lum_lost_prev"] = self.device_tensor("lum_lost_prev")
+            fields["scaspe"] = [self.device_tensor("scaspe", il) for il in range(self.L)]
+        parallel.rt_mpi(rt, fields, self.group)
+
+    def attach_process_group(self, group=None):
+        """Use an initialised torch.distributed group (backend nccl = RCCL) for the stage-end reductions."""
+        import torch.distributed as dist
+        assert dist.is_initialized() and dist.get_world_size(group) == self.np_mpi
+        self.group, self.use_dist = group, self.np_mpi > 1
+
+    def device_tensor(self, which: str, il: int = 0):
+        """Zero-copy torch view of a device field (drt_device_ptr)."""
+        from . import parallel
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L_.drt_device_ptr(self.h, A[which], il, C.byref(p), C.byref(n)))
+        return parallel.alias_device(p.value, n.value, self.device)
 
     def scatt_prepare(self) -> bool:
         """rt_prepare for rtt_scatt; returns cnflag."""
@@ -210,7 +242,7 @@ class DartRayGPU:
     def _count(self, which, il):
         NL = self.N * self.L
         return {"u_fest": NL, "u_final": NL, "lumcell": NL, "dens": NL, "dens_stars": NL, "lum_lost": self.L,
-                "tot_rad_en": self.L, "i_obs": self.ndir * (self.N + self.nsrc) * self.L,
+                "tot_rad_en": self.L, "lum_lost_prev": self.L, "i_obs": self.ndir * (self.N + self.nsrc) * self.L,
                 "scaspe": None, "scaspe_tot": None, "scaspe_prev": None}[which]
 
     def get_array(self, which: str, il: int = 0) -> np.ndarray:

@@ -57,6 +57,7 @@ extern "C" {
 #define DRT_A_DENS 9        /* dens_arr(0:lnum-1,0:tot_ncell-1)              :62  */
 #define DRT_A_DENS_STARS 10 /* dens_stars_arr                                :70  */
 #define DRT_A_TOT_RAD_EN 11 /* tot_rad_en(0:lnum-1)           rt_routines.f90:33  */
+#define DRT_A_LUM_LOST_PREV 12 /* lum_lost_prev(0:lnum-1)     rt_routines.f90:133 */
 
 typedef struct drt_ctx drt_ctx;
 
@@ -83,6 +84,10 @@ typedef struct drt_counters {
     int64_t rays;          /* calls of ray_tracing */
     int64_t deposits;      /* intersections with length /= 0 (:1731) */
     int64_t scaspe_adds;   /* (intersection, wavelength) pairs that issued a scaspe axpy (:2656) */
+    int64_t lambda_deposits; /* (deposit, active wavelength) pairs: one dens_arr read each (:2380) */
+    int64_t u_adds;        /* u_fest / u_final read-modify-writes issued (:2445, :2499) */
+    int64_t u_reads;       /* u_fest reads of the blocked branch (:2477) */
+    int64_t scaspe_slots;  /* scaspe elements read-modify-written (sum of npix over scaspe_adds) */
     int64_t sources;       /* sources processed by the last rt_loop */
     double kernel_ms;      /* device time of the ray-tracing kernel(s) of the last rt_loop (hipEvent) */
     int64_t launches;      /* kernel launches behind kernel_ms */
@@ -128,6 +133,9 @@ int drt_rt_mpi(drt_ctx *ctx, int32_t rt_type);
  * otherwise). count must equal the field's element count. */
 int drt_get_array(drt_ctx *ctx, int32_t which, int32_t il, double *host, size_t count);
 int drt_set_array(drt_ctx *ctx, int32_t which, int32_t il, const double *host, size_t count);
+/* Device address and element count of a field, for hosts that run the stage-end reductions
+ * themselves (e.g. torch.distributed / RCCL on the same buffers). The memory stays owned by ctx. */
+int drt_device_ptr(drt_ctx *ctx, int32_t which, int32_t il, void **dev_ptr, size_t *count);
 /* npix_arr, npix_hp_arr, kp_sca_arr of wavelength il (set_npix_arr, rt_routines.f90:5235) */
 int drt_get_npix(const drt_ctx *ctx, int32_t il, int32_t *npix, int32_t *npix_hp, int32_t *kp);
 int drt_get_src_cell(const drt_ctx *ctx, int32_t *src_cell /* [tot_ncell] */, double *ccoord_p_src /* (3,nsrc) or NULL */);

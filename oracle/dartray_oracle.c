@@ -1358,6 +1358,7 @@ double *orc_scaspe_tot(orc_ctx *c, int il) { return c->scaspe_tot[il]; }
 double *orc_scaspe_prev(orc_ctx *c, int il) { return c->scaspe_prev[il]; }
 double *orc_lumcell(orc_ctx *c) { return c->lumcell; }
 double *orc_lum_lost(orc_ctx *c) { return c->lum_lost; }
+double *orc_lum_lost_prev(orc_ctx *c) { return c->lum_lost_prev; }
 double *orc_i_obs(orc_ctx *c) { return c->i_obs; }
 int32_t *orc_src_cell(orc_ctx *c) { return c->src_cell; }
 double *orc_p_src_pos(orc_ctx *c) { return c->p_src_pos; }

@@ -84,6 +84,7 @@ double *orc_scaspe_tot(orc_ctx *c, int il);
 double *orc_scaspe_prev(orc_ctx *c, int il);
 double *orc_lumcell(orc_ctx *c);           /* [N][L] */
 double *orc_lum_lost(orc_ctx *c);          /* [L] */
+double *orc_lum_lost_prev(orc_ctx *c);     /* [L] */
 double *orc_i_obs(orc_ctx *c);             /* [ndir][N+nsrc][L] */
 int32_t *orc_src_cell(orc_ctx *c);         /* [N] */
 double *orc_p_src_pos(orc_ctx *c);         /* [nsrc][3] after the tol_p nudge */

@@ -57,7 +57,7 @@ def lib():
             getattr(L, fn).restype = C.c_int
         L.orc_en_lim.argtypes = [C.c_void_p]
         L.orc_en_lim.restype = C.c_double
-        for fn in ("orc_u_fest", "orc_u_final", "orc_lumcell", "orc_lum_lost", "orc_i_obs", "orc_p_src_pos"):
+        for fn in ("orc_u_fest", "orc_u_final", "orc_lumcell", "orc_lum_lost", "orc_lum_lost_prev", "orc_i_obs", "orc_p_src_pos"):
             getattr(L, fn).argtypes = [C.c_void_p]
             getattr(L, fn).restype = C.POINTER(C.c_double)
         for fn in ("orc_scaspe", "orc_scaspe_tot", "orc_scaspe_prev"):
@@ -122,6 +122,8 @@ class Oracle:
     def lumcell(self): return self._arr(self.L_.orc_lumcell(self.h), (self.N, self.L))
     @property
     def lum_lost(self): return self._arr(self.L_.orc_lum_lost(self.h), (self.L,))
+    @property
+    def lum_lost_prev(self): return self._arr(self.L_.orc_lum_lost_prev(self.h), (self.L,))
     @property
     def i_obs(self): return self._arr(self.L_.orc_i_obs(self.h), (max(self.ndir, 1), self.N + self.nsrc, self.L))
     @property

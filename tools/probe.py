@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Developer tool: time every stage of a TRUST-I run on the GPU.
+usage: python tools/probe.py <max_lvl> <nlambda> [tau_z] [max_iter]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+pkg = ge._load_pkg()
+max_lvl, nl = int(sys.argv[1]), int(sys.argv[2])
+tau = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+max_it = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+wl = list(range(32)) if nl == 32 else ([11] if nl == 1 else list(np.linspace(0, 21, nl).astype(int)))
+t0 = time.time()
+case = pkg.grids.trusti_case(tau_z=tau, max_lvl=max_lvl, wavelengths=wl, max_sca_iterations=max_it)
+print(f"case N={case.tree.ncell} leaves={case.tree.leaf.sum()} L={case.lnum} build {time.time()-t0:.2f}s", flush=True)
+g = pkg.DartRayGPU(case, arena_bytes=int(os.environ.get("ARENA_GB", "8")) << 30)
+def stage(name, fn):
+    g.reset_counters(); t = time.time(); fn(); dt = time.time() - t
+    c = g.counters()
+    bytes_alg = 40 * c["intersections"] + 8 * c["lambda_deposits"] + 16 * c["u_adds"] + 8 * c["u_reads"] + 16 * c["scaspe_slots"]
+    ms = c["kernel_ms"]
+    print(f"{name:14s} wall {dt*1e3:9.1f} ms kernel {ms:9.2f} ms src {c['sources']:7d} inter {c['intersections']:12d} rays {c['rays']:11d} "
+          f"sca {c['scaspe_adds']:12d} | {c['intersections']/max(ms,1e-9)*1e3:.3e} inter/s  {bytes_alg/max(ms,1e-9)*1e3/1e9:8.1f} GB/s alg", flush=True)
+g.rt_prepare("start")
+print("npix", g.npix)
+stage("precalc_cell", lambda: g.rt_loop("precalc_cell")); stage("precalc_src", lambda: g.rt_loop("precalc_src")); g.rt_mpi("precalc_src")
+g.rt_prepare("prep_part2")
+stage("dir_cell", lambda: g.rt_loop("dir_cell")); stage("dir_src", lambda: g.rt_loop("dir_src")); g.rt_mpi("dir_src")
+stage("iobs_dir", lambda: (g.rt_loop_iobs("i_obs_dir_cell"), g.rt_loop_iobs("i_obs_dir_src")))
+it = 0
+while not g.scatt_prepare():
+    it += 1
+    stage(f"scatt{it}", lambda: g.rt_loop("scatt")); g.rt_mpi("scatt")
+print("iterations", g.iterations, "lum_lost/L", g.lum_lost / case.p_src_lum[0])
