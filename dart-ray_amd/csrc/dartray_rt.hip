@@ -94,7 +94,7 @@ struct drt_ctx {
     DevProblem* d_prob = nullptr;
     DevProblem hprob{};
     char* d_arena = nullptr;
-    size_t arena_bytes = 4ull << 30;
+    size_t arena_bytes = 16ull << 30;
     int waves = 0, cap = 0, hcap = 0;
     unsigned long long wave_stride = 0;
     unsigned long long* d_counters = nullptr;
@@ -369,7 +369,7 @@ static void h_pix2ang_nest(int nside, int ipix, double* theta, double* phi)
 static int build_dir_tables(drt_ctx* c)
 {
     if (c->tab_max_level > 0 && c->d_ring_tab[c->tab_max_level]) return DRT_OK;
-    int kmax = 10;  // nside 1024
+    int kmax = 11;  // nside 2048: ~270 MB of tables; rays finer than that raise ERR_TABLE
     if (const char* e = getenv("DRT_TAB_NSIDE")) { int n = atoi(e); kmax = 2; while ((1 << (kmax + 1)) <= n && kmax < 13) kmax++; }
     const double halfpi = (double)asinf(1.0f);
     for (int k = 1; k <= kmax; k++) {
@@ -430,6 +430,11 @@ static int upload_problem(drt_ctx* c)
         P.scaspe_prev[il] = il < (int)c->d_scaspe_prev.size() ? c->d_scaspe_prev[il] : nullptr;
         P.scaspe_tot[il] = il < (int)c->d_scaspe_tot.size() ? c->d_scaspe_tot[il] : nullptr;
         P.tab[il] = (c->ik[il] >= 0 && c->ik[il] < (int)c->d_tab.size()) ? c->d_tab[c->ik[il]] : nullptr;
+        P.tabid[il] = P.tab[il] ? c->ik[il] : -1;
+    }
+    for (int u = 0; u < 4; u++) {
+        P.utab[u] = (u < (int)c->d_tab.size()) ? c->d_tab[u] : nullptr;
+        P.utab_np[u] = (u < (int)c->npix_unique.size()) ? c->npix_unique[u] : 0;
     }
     P.arena = c->d_arena;
     P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task;
@@ -441,9 +446,30 @@ static int upload_problem(drt_ctx* c)
     return DRT_OK;
 }
 
+template <int LP> static int stage_blocks_per_cu()
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_kernel<LP>, 256, 0) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
 static int ensure_arena(drt_ctx* c)
 {
-    if (c->waves <= 0) c->waves = c->ncu * 8;
+    if (c->waves <= 0) {
+        // persistent waves: exactly as many as the chip keeps resident (more would only wait for a slot
+        // while dividing the queue arena further)
+        int nb = 1;
+        switch (c->LP) {
+        case 1: nb = stage_blocks_per_cu<1>(); break;
+        case 2: nb = stage_blocks_per_cu<2>(); break;
+        case 4: nb = stage_blocks_per_cu<4>(); break;
+        case 8: nb = stage_blocks_per_cu<8>(); break;
+        case 16: nb = stage_blocks_per_cu<16>(); break;
+        case 32: nb = stage_blocks_per_cu<32>(); break;
+        default: nb = stage_blocks_per_cu<64>(); break;
+        }
+        c->waves = c->ncu * nb * 4;
+    }
     c->waves = (c->waves + 3) / 4 * 4;
     if (c->d_arena) return DRT_OK;
     HIPCHK(c, hipMalloc((void**)&c->d_arena, c->arena_bytes));
@@ -483,6 +509,7 @@ static const char* trace_error_text(int e)
     if (e & ERR_NSIDE) return "nside out of range (healpix_routines.f90:54)";
     if (e & ERR_STEPS) return "step limit reached";
     if (e & ERR_MERGE) return "inconsistent sibling table while merging low rays";
+    if (e & ERR_TABLE) return "ray finer than the HEALPix direction tables (set DRT_TAB_NSIDE to a larger power of two)";
     return "unknown device error";
 }
 
@@ -564,12 +591,15 @@ static int prepare_part2(drt_ctx* c)
     c->d_tab.assign(c->nuniq, nullptr);
     for (int u = 0; u < c->nuniq; u++) {
         int n = c->npix_unique[u], nhp = n - c->ndir, nside_sca = 1 << c->kp_unique[u];
-        std::vector<double> t(4ull * n);
+        // unit vectors of the scaspe slots: HEALPix pixel centres, then the observer directions
+        // (create_scaspe, rt_routines.f90:2827-2848); calc_ads_arr's cosine (:2294) is their dot product
+        // with the ray direction
+        std::vector<double> t(3ull * n);
         for (int j = 0; j < n; j++) {
             double th, ph;
             if (j < nhp) h_pix2ang_nest(nside_sca, j, &th, &ph);
             else { th = c->dir_out[j - nhp]; ph = c->dir_out[c->ndir + (j - nhp)]; }
-            t[j] = cos(th); t[n + j] = sin(th); t[2ull * n + j] = cos(ph); t[3ull * n + j] = sin(ph);
+            t[j] = sin(th) * cos(ph); t[n + j] = sin(th) * sin(ph); t[2ull * n + j] = cos(th);
         }
         if ((rc = dev_upload(c, &c->d_tab[u], t.data(), t.size()))) return rc;
     }
@@ -1032,6 +1062,15 @@ extern "C" int drt_debug_trace(drt_ctx* c, int capacity, int* out, int* count)
         HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(int)));
     }
     if (c->prepared) return upload_problem(c);
+    return DRT_OK;
+}
+
+// Developer aid: raw device counters (slots 8.. hold the phase timers of a -DDRT_PROFILE build).
+extern "C" int drt_debug_counters(drt_ctx* c, unsigned long long* out, int n)
+{
+    if (!c || !out || n > CNT_N) return DRT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->d_counters, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return DRT_OK;
 }
 

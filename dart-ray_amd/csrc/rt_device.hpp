@@ -19,10 +19,10 @@ enum { RTT_PRECALC_CELL = 1, RTT_PRECALC_SRC = 2, RTT_DIR_CELL = 5, RTT_I_OBS_DI
 enum { RAY_HIGH = 0, RAY_LOW = 1, RAY_RECO = 2, RAY_GONE = 3 };
 enum { ST_CONT = 0, ST_GO_HIGH = 1, ST_GONE = 2, ST_GO_LOW = 3, ST_OUT = 4 };
 // error bits
-enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64 };
+enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64, ERR_TABLE = 128 };
 
 // counters[] slots
-enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7, CNT_N = 8 };
+enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7, CNT_N = 24 };
 
 struct DevProblem {
     int N, max_lvl, base0, base1, L, nsrc, ndir, pabs_max;
@@ -55,7 +55,10 @@ struct DevProblem {
     double* scaspe[DRT_MAXL];             // [N][npix]
     const double* scaspe_prev[DRT_MAXL];
     const double* scaspe_tot[DRT_MAXL];
-    const double* tab[DRT_MAXL];          // [4][npix]: cos(theta), sin(theta), cos(phi), sin(phi); null if isotropic
+    const double* tab[DRT_MAXL];          // [3][npix]: unit vectors of the scaspe slots (x, y, z); null if isotropic
+    int tabid[DRT_MAXL];                  // index of the slot table (kp_unique order), -1 if isotropic
+    const double* utab[4];                // the unique slot tables, utab_np[] slots each
+    int utab_np[4];
     // per-wave ray-queue arena
     char* arena;
     unsigned long long* counters;
@@ -114,42 +117,13 @@ __device__ __forceinline__ uint32_t spread_bits(uint32_t v)
     return v;
 }
 
-__device__ inline void pix2ang_nest(const DevProblem& P, int nside, int ipix, double& theta, double& phi)
-{
-    const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
-    const int jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
-    int npface = nside * nside, nl4 = 4 * nside;
-    int face_num = ipix / npface;
-    int ipf = ipix - face_num * npface;
-    double fn = (double)nside;
-    double fact1 = 1.0 / (3.0 * fn * fn);
-    double fact2 = 2.0 / (3.0 * fn);
-    int ix = (int)compact_even_bits((uint32_t)ipf);
-    int iy = (int)compact_even_bits((uint32_t)ipf >> 1);
-    int jrt = ix + iy, jpt = ix - iy;
-    int jr = jrll[face_num] * nside - jrt - 1;
-    int nr, kshift;
-    double z;
-    if (jr < nside) { nr = jr; z = 1.0 - nr * fact1 * nr; kshift = 0; }
-    else if (jr <= 3 * nside) { nr = nside; z = (2 * nside - jr) * fact2; kshift = (jr - nside) & 1; }
-    else { nr = nl4 - jr; z = -1.0 + nr * fact1 * nr; kshift = 0; }
-    theta = acos(z);
-    int jp = (jpll[face_num] * nr + jpt + 1 + kshift) / 2;
-    if (jp > nl4) jp -= nl4;
-    if (jp < 1) jp += nl4;
-    phi = (jp - (kshift + 1) * 0.5) * (P.halfpi / nr);
-}
-
 // Pixel centre with its sines and cosines. Uses the host-built tables when the level has them.
 struct PixDir { double theta, phi, st, ct, sp, cp; };
-__device__ inline void pix2ang_nest_sc(const DevProblem& P, int nside, int ipix, PixDir& o)
+// Returns false when `nside` is finer than the host-built tables (the caller raises ERR_TABLE).
+__device__ inline bool pix2ang_nest_sc(const DevProblem& P, int nside, int ipix, PixDir& o)
 {
     const int k = 31 - __clz(nside);
-    if (k > P.tab_max_level) {
-        pix2ang_nest(P, nside, ipix, o.theta, o.phi);
-        o.st = sin(o.theta); o.ct = cos(o.theta); o.sp = sin(o.phi); o.cp = cos(o.phi);
-        return;
-    }
+    if (k > P.tab_max_level) { o.theta = o.phi = 0; o.st = o.sp = 0; o.ct = o.cp = 1; return false; }
     const int jrll[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
     const int jpll[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
     int npface = nside * nside, nl4 = 4 * nside;
@@ -170,15 +144,34 @@ __device__ inline void pix2ang_nest_sc(const DevProblem& P, int nside, int ipix,
     o.theta = rt[0]; o.st = rt[1]; o.ct = rt[2];
     const double* pt = (kshift == 0) ? (P.phi0_tab[k] + 3ull * (2ull * nr * (nr - 1) + (jp - 1))) : (P.phi1_tab[k] + 3ull * (jp - 1));
     o.phi = pt[0]; o.sp = pt[1]; o.cp = pt[2];
+    return true;
+}
+
+// Exact remainder of non-negative doubles, a - trunc(a/b)*b (Fortran MOD, rt_routines.f90:1836), without
+// the library's fmod: one fma gives the exact remainder for the rounded quotient, then at most one
+// correction step (both exact, the remainder of two doubles is representable).
+// x**(-1.5) for the Henyey-Greenstein weights (calc_ffn_arr, rt_routines.f90:2254): hardware
+// reciprocal square root refined by two Newton steps (to ~2 ulp), then cubed.
+__device__ __forceinline__ double pow_m1p5(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y * y * y;
+}
+
+__device__ __forceinline__ double fmod_pos(double a, double b)
+{
+    double q = trunc(a / b);
+    double r = __builtin_fma(-q, b, a);
+    if (r < 0) r += b;
+    else if (r >= b) r -= b;
+    return r;
 }
 
 // ang2pix_nest with z = cos(theta) supplied by the caller (healpix_routines.f90:269)
 __device__ inline int ang2pix_nest_z(const DevProblem& P, int nside, double z, double phi);
-
-__device__ inline int ang2pix_nest(const DevProblem& P, int nside, double theta, double phi)
-{
-    return ang2pix_nest_z(P, nside, cos(theta), phi);
-}
 
 __device__ inline int ang2pix_nest_z(const DevProblem& P, int nside, double z, double phi)
 {

@@ -73,11 +73,22 @@ struct Ray {
     double pa0, pa1, pa2;     // pabs_arr
     double prev;
     double I;                 // ray_intensity of this lane's wavelength
-    double tot_hg;            // HG normalisation (calc_ffn_arr, rt_routines.f90:2258)
-    double cd, sd, ca, sa;    // cos/sin of the direction used by calc_ads_arr
+    double tot_hg;            // HG normalisation: sum over the HEALPix slots of x**-1.5 (calc_ffn_arr, rt_routines.f90:2258)
+    double nx, ny, nz;        // unit vector of the direction used by calc_ads_arr (:2294)
 };
 
-struct WaveCounters { unsigned long long inter, rays, deps, sca, lamdep, uadd, uread, slots; };
+struct WaveCounters { unsigned long long inter, rays, deps, sca, lamdep, uadd, uread, slots;
+#ifdef DRT_PROFILE
+    unsigned long long t_setup, t_step, t_flush, t_park, t_next, t_commit, t_extract, t_total, n_steps, n_busy_lanes, n_groups, n_deps;
+#endif
+};
+#ifdef DRT_PROFILE
+#define TSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime()
+#define TACC(field, t0, t1) wc.field += (t1) - (t0)
+#else
+#define TSTAMP(v)
+#define TACC(field, t0, t1)
+#endif
 
 // calc_psel (rt_routines.f90:2307-2351)
 __device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S, Ray& r, double& psel, int& isel)
@@ -183,7 +194,7 @@ __device__ __forceinline__ bool step_axis(const DevProblem& P, uint32_t& w, int 
             int v = (int)(bb / cellsize);
             if (v == b) v = b - 1;
             w = nib_set(w, j, v);
-            bb = fmod(bb, cellsize);
+            bb = (bb >= 0) ? fmod_pos(bb, cellsize) : -fmod_pos(-bb, cellsize);
         }
     }
     return true;
@@ -207,9 +218,10 @@ __device__ __forceinline__ bool wall_hit(const DevProblem& P, int rt, int cc)
 // r.I / lum_lost. `live` = lane holds a real wavelength of a busy ray.
 __device__ __forceinline__ int deposit(const DevProblem& P, int rt, const SrcInfo& S, Ray& r, bool live, int il, int level,
                                        double length, double psel, unsigned long long grp, double& en_sca,
-                                       double& lum_lost_acc, WaveCounters& wc)
+                                       double& u_add, double& lum_lost_acc, WaveCounters& wc)
 {
     en_sca = 0.0;
+    u_add = 0.0;
     const int cc = r.cc, nc = S.nc;
     const bool act = live && r.lam_active;
     const unsigned long long idx = (unsigned long long)cc * P.L + il;
@@ -263,7 +275,8 @@ __device__ __forceinline__ int deposit(const DevProblem& P, int rt, const SrcInf
         } else if ((beam_f / P.bm_par_max < beam_i) || (level <= 8) || r.flag_beam) {
             if (act) {
                 double v = i_av * length / P.cs / vol_f * S.area_i * beam_i;
-                if (v != 0.0) { atomicAdd(&P.u_final[idx], v); wc.uadd++; }
+                u_add = v;
+                if (v != 0.0) wc.uadd++;
                 double k = P.ksca[il];
                 if (cc != nc) {
                     if (tau_c > P.tau_thin) en_sca = I * (1.0 - ex) * k * S.area_i * beam_i;
@@ -284,40 +297,105 @@ __device__ __forceinline__ int deposit(const DevProblem& P, int rt, const SrcInf
     return ST_CONT;
 }
 
-// Wave-cooperative process_scatt_rad (rt_routines.f90:2638-2726): for every lane with en_sca != 0
-// broadcast its cell / wavelength / energy / direction and let the 64 lanes act as the scaspe
-// slots of that cell. Weights are those of calc_ffn_arr (:2252-2266), recomputed per slot.
+// Wave-cooperative process_scatt_rad (rt_routines.f90:2638-2726) + u_final update (:2497-2505).
+// For every lane holding a deposit, its cell / wavelength / energy / direction are broadcast with
+// readlane and the 64 lanes become the scaspe slots of that cell: lanes 0..npix-1 add
+// en_sca * weight(slot) to scaspe(:,cc) (contiguous f64 atomics, one instruction), lane 63 adds the
+// energy-density increment to u_final(il,cc) in the same instruction. Slot unit vectors of the
+// first two slot tables live in registers (rtab*), so a round touches no memory but the atomics.
+// Weights: w_p = x_p**-1.5 / sum_q x_q**-1.5, x = 1 + g^2 - 2 g cos(angle) (calc_ffn_arr :2252-2260).
+struct RegTabs { double x0, y0, z0, x1, y1, z1; };
+#ifdef DRT_NO_ATOMICS  // diagnostic build: keep the values alive, skip the memory operation
+#define FLUSH_ATOMIC(addr, v) asm volatile("" ::"v"(addr), "v"(v))
+#else
+#define FLUSH_ATOMIC(addr, v) atomicAdd(addr, v)
+#endif
+
 template <int LP>
-__device__ __forceinline__ void flush_scaspe(const DevProblem& P, const Ray& r, double e, WaveCounters& wc)
+__device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r, const RegTabs& T, double e, double u_add,
+                                               WaveCounters& wc)
 {
     const int lane = lane_id();
-    unsigned long long pend = __ballot(e != 0.0);
-    wc.sca += (unsigned long long)__popcll(pend);
+    unsigned long long pend = __ballot(e != 0.0 || u_add != 0.0);
+#ifdef DRT_PROFILE
+    {   // statistics: how many distinct (cell, wavelength) targets do this step's deposits have?
+        unsigned long long q = pend;
+        while (q) {
+            const int s0 = __ffsll((long long)q) - 1;
+            const int c0 = bcast_i(r.cc, s0);
+            q &= ~__ballot(r.cc == c0 && (lane % LP) == (s0 % LP));
+            wc.n_groups++;
+        }
+        wc.n_deps += __popcll(pend);
+    }
+#endif
+    const bool mine = (e != 0.0 || u_add != 0.0);
+    const int il = lane % LP;
     while (pend) {
-        int src = __ffsll((long long)pend) - 1;
-        pend &= pend - 1;
+        const int src = __ffsll((long long)pend) - 1;
         const int il_b = src % LP;
         const int cc_b = bcast_i(r.cc, src);
-        const double e_b = bcast_d(e, src);
+        // every lane of this step that deposits into the same (cell, wavelength) is summed on chip and
+        // leaves the wave as one read-modify-write
+        unsigned long long grp = __ballot(mine && r.cc == cc_b && il == il_b);
+        pend &= ~grp;
         const int np = P.npix[il_b];
-        wc.slots += (unsigned long long)np;
-        const double* tab = P.tab[il_b];
-        double* dst = P.scaspe[il_b] + (unsigned long long)cc_b * np;
-        if (tab) {
-            const double tot_b = bcast_d(r.tot_hg, src);
-            const double cd = bcast_d(r.cd, src), sd = bcast_d(r.sd, src), ca = bcast_d(r.ca, src), sa = bcast_d(r.sa, src);
-            const double g = P.g[il_b];
-            const double konst = (1.0 - g * g) / P.npix_hp[il_b];
-            for (int p = lane; p < np; p += 64) {
-                double ads = (tab[p] * cd + tab[np + p] * sd * (tab[2 * np + p] * ca + tab[3 * np + p] * sa));
-                double x = 1.0 + g * g - 2.0 * g * ads;
-                double f = 1.0 / (x * sqrt(x));
-                f = konst * f;
-                f = f / tot_b;
-                atomicAdd(&dst[p], e_b * f);
+        double* srow = P.scaspe[il_b] + (unsigned long long)cc_b * np;
+        double* uaddr = P.u_final + (unsigned long long)cc_b * P.L + il_b;
+        const int tid = P.tabid[il_b];
+        const double g = P.g[il_b];
+        const double ga = 1.0 + g * g, gb = 2.0 * g;
+        if (np <= 63 && tid <= 1) {
+            const double px = tid == 1 ? T.x1 : T.x0, py = tid == 1 ? T.y1 : T.y0, pz = tid == 1 ? T.z1 : T.z0;
+            double acc = 0.0, su = 0.0;
+            while (grp) {
+                const int m = __ffsll((long long)grp) - 1;
+                grp &= grp - 1;
+                const double e_b = bcast_d(e, m);
+                su += bcast_d(u_add, m);
+                if (e_b != 0.0) {
+                    wc.sca++;
+                    wc.slots += (unsigned long long)np;
+                    if (tid < 0) acc += e_b;  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
+                    else {
+                        const double nx = bcast_d(r.nx, m), ny = bcast_d(r.ny, m), nz = bcast_d(r.nz, m);
+                        const double C = e_b / bcast_d(r.tot_hg, m);
+                        acc += C * pow_m1p5(ga - gb * (px * nx + py * ny + pz * nz));
+                    }
+                }
             }
+            double* addr = (lane == 63) ? uaddr : &srow[lane];
+            const double v = (lane == 63) ? su : acc;
+            if ((lane < np || lane == 63) && v != 0.0) FLUSH_ATOMIC(addr, v);
         } else {
-            for (int p = lane; p < np; p += 64) atomicAdd(&dst[p], e_b);
+            const double* tab = P.tab[il_b];
+            double su = 0.0;
+            for (int p0 = 0; p0 < np; p0 += 64) {
+                const int p = p0 + lane;
+                double px = 0, py = 0, pz = 0;
+                if (tab && p < np) { px = tab[p]; py = tab[np + p]; pz = tab[2 * np + p]; }
+                double acc = 0.0;
+                unsigned long long gm = grp;
+                while (gm) {
+                    const int m = __ffsll((long long)gm) - 1;
+                    gm &= gm - 1;
+                    const double e_b = bcast_d(e, m);
+                    if (p0 == 0) {
+                        su += bcast_d(u_add, m);
+                        if (e_b != 0.0) { wc.sca++; wc.slots += (unsigned long long)np; }
+                    }
+                    if (e_b != 0.0) {
+                        if (!tab) acc += e_b;
+                        else {
+                            const double nx = bcast_d(r.nx, m), ny = bcast_d(r.ny, m), nz = bcast_d(r.nz, m);
+                            const double C = e_b / bcast_d(r.tot_hg, m);
+                            acc += C * pow_m1p5(ga - gb * (px * nx + py * ny + pz * nz));
+                        }
+                    }
+                }
+                if (p < np && acc != 0.0) FLUSH_ATOMIC(&srow[p], acc);
+            }
+            if (lane == 63 && su != 0.0) FLUSH_ATOMIC(uaddr, su);
         }
     }
 }
@@ -338,7 +416,7 @@ __device__ __forceinline__ void flush_scaspe(const DevProblem& P, const Ray& r, 
 template <int LP>
 __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in,
                             int n_in, const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
-                            int* __restrict__ ostat, int level, double& lum_lost_acc, WaveCounters& wc, int& err)
+                            int* __restrict__ ostat, int level, const RegTabs& T, double& lum_lost_acc, WaveCounters& wc, int& err)
 {
     constexpr int R = 64 / LP;
     constexpr unsigned long long GRP0 = (LP == 64) ? ~0ull : ((1ull << LP) - 1ull);
@@ -358,7 +436,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
     Ray r;
     r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
     r.lam_active = false; r.cx = r.cy = r.cz = 0; r.inc0 = r.inc1 = r.inc2 = 0; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
-    r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.cd = r.sd = r.ca = r.sa = 0;
+    r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
     long long guard = 0;
 
     for (int chunk_base = 0; chunk_base < n_items; chunk_base += a.cap) {
@@ -374,6 +452,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
             if (!more && n_busy == 0) break;
             if (++guard > (1ll << 26)) { err |= ERR_STEPS; break; }
 
+            TSTAMP(ts0);
             // ---- refill idle ray slots -----------------------------------------------------------
             if (more && (n_busy == 0 || 2 * (R - n_busy) >= R)) {
                 const unsigned long long idle_leaders = (~busy_b) & leaders;
@@ -391,7 +470,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                         int ipix_dir = (int)in.ipix[parent];
                         if (mode == 0 && type == RAY_HIGH) ipix_dir = 4 * ipix_dir + child;
                         PixDir pd;
-                        pix2ang_nest_sc(P, level, ipix_dir, pd);
+                        if (!pix2ang_nest_sc(P, level, ipix_dir, pd)) err |= ERR_TABLE;
                         const double theta = pd.theta, phi = pd.phi;
                         const int cc_old = in.cc[parent];
                         const double prev_ray = in.prev[parent];
@@ -440,24 +519,22 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                             r.tot_hg = 1.0;
                             if (a.scatter) {
                                 // calc_ffn_arr (rt_routines.f90:2186-2281); "reco" rays read table row 1
-                                double cd = cos_dl, sd = sin_dl, ca = cos_al, sa = sin_al;
+                                double nx = d0, ny = d1, nz = d2;
                                 if (is_reco && level <= 256) {
                                     PixDir p1;
                                     pix2ang_nest_sc(P, level, 1, p1);
-                                    sd = p1.st; cd = p1.ct; sa = p1.sp; ca = p1.cp;
+                                    nx = p1.st * p1.cp; ny = p1.st * p1.sp; nz = p1.ct;
                                 }
-                                r.cd = cd; r.sd = sd; r.ca = ca; r.sa = sa;
+                                r.nx = nx; r.ny = ny; r.nz = nz;
                                 const double* tab = lam_ok ? P.tab[il] : nullptr;
                                 if (r.lam_active && tab) {
                                     const double g = P.g[il];
                                     const int np = P.npix[il], hp = P.npix_hp[il];
-                                    const double konst = (1.0 - g * g) / hp;
+                                    const double ga = 1.0 + g * g, gb = 2.0 * g;
                                     double tot = 0;
                                     for (int p = 0; p < hp; p++) {
-                                        double ads = (tab[p] * cd + tab[np + p] * sd * (tab[2 * np + p] * ca + tab[3 * np + p] * sa));
-                                        double x = 1.0 + g * g - 2.0 * g * ads;
-                                        double f = 1.0 / (x * sqrt(x));
-                                        tot += konst * f;
+                                        double ads = tab[p] * nx + tab[np + p] * ny + tab[2 * np + p] * nz;
+                                        tot += pow_m1p5(ga - gb * ads);
                                     }
                                     r.tot_hg = tot;
                                 }
@@ -469,9 +546,14 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                 }
             }
 
+            TSTAMP(ts1);
+            TACC(t_setup, ts0, ts1);
+#ifdef DRT_PROFILE
+            wc.n_steps++; wc.n_busy_lanes += __popcll(__ballot(busy));
+#endif
             // ---- one ray-cell intersection for every busy slot ---------------------------------------
             int status = ST_CONT;
-            double en_sca = 0.0, psel = 0.0;
+            double en_sca = 0.0, u_add = 0.0, psel = 0.0;
             int isel = 0;
             if (busy) {
                 if (leader) wc.inter++;
@@ -482,10 +564,14 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                 if (r.cc != S.nc && r.cc != r.cc_new) r.flag_beam = false;
                 if (length != 0. && status == ST_CONT) {
                     if (leader) wc.deps++;
-                    status = deposit(P, rt, S, r, lam_ok, il, level, length, psel, grp, en_sca, lum_lost_acc, wc);
+                    status = deposit(P, rt, S, r, lam_ok, il, level, length, psel, grp, en_sca, u_add, lum_lost_acc, wc);
                 }
             }
-            if (a.scatter) flush_scaspe<LP>(P, r, en_sca, wc);
+            TSTAMP(ts2);
+            TACC(t_step, ts1, ts2);
+            if (a.scatter) flush_deposits<LP>(P, r, T, en_sca, u_add, wc);
+            TSTAMP(ts3);
+            TACC(t_flush, ts2, ts3);
 
             // ---- blocked rays are parked at their item's index (add_to_high/low_ray_list, ray_list.f90:463-579)
             if (busy && (status == ST_GO_HIGH || status == ST_GO_LOW)) {
@@ -503,6 +589,8 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                 if (lam_ok) stg.lum[(unsigned long long)my_item * LP + il] = r.I * S.norm;
             }
             if (busy && status != ST_CONT) busy = false;
+            TSTAMP(ts4);
+            TACC(t_park, ts3, ts4);
 
             // ---- next cell --------------------------------------------------------------------------------
             if (busy) {
@@ -517,8 +605,11 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                 if (!inside) busy = false;
                 else if (!ccindd_to_cc(P, r.cx, r.cy, r.cz, r.cc, r.clvl)) { err |= ERR_CELL_NOT_FOUND; busy = false; }
             }
+            TSTAMP(ts5);
+            TACC(t_next, ts4, ts5);
         }
         wave_fence();
+        TSTAMP(tc0);
 
         // ---- commit the parked rays in item order ------------------------------------------------------
         for (int base = 0; base < chunk_end - chunk_base; base += 64) {
@@ -539,6 +630,8 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
             nL += __popcll(bl);
         }
         wave_fence();
+        TSTAMP(tc1);
+        TACC(t_commit, tc0, tc1);
         if (err & ERR_STEPS) break;
     }
 }
@@ -747,8 +840,13 @@ __device__ void extract_low(const DevProblem& P, const StageArgs& a, const ListV
 // ------------------------------------------------------------------------------------------------
 // rt_loop (rt_routines.f90:985-1058) + main_dir_loop (:1343-1467): persistent waves pull tasks.
 // ------------------------------------------------------------------------------------------------
+// 2 waves per SIMD: the queue appends and the f64 atomics leave long in-order vmcnt waits that a
+// second resident wave overlaps (measured +10 % over one wave per SIMD, rocprof: 52 % SQ_WAIT_ANY)
+#ifndef DRT_MIN_WAVES
+#define DRT_MIN_WAVES 2
+#endif
 template <int LP>
-__global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restrict__ Pp, StageArgs a)
+__global__ void __launch_bounds__(256, DRT_MIN_WAVES) rt_stage_kernel(const DevProblem* __restrict__ Pp, StageArgs a)
 {
     const DevProblem& P = *Pp;
     const int lane = lane_id();
@@ -764,8 +862,15 @@ __global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restr
     const int tasks_per_src = 48 / G;
     const int ntasks = a.nsources * tasks_per_src;
     const int rt = a.rt_type;
-    WaveCounters wc = {0, 0, 0, 0, 0, 0, 0, 0};
+    WaveCounters wc = {};
     int err = 0;
+    TSTAMP(tk0);
+    // slot unit vectors of the first two scaspe slot tables, one slot per lane
+    RegTabs T = {0, 0, 0, 0, 0, 0};
+    if (a.scatter) {
+        if (P.utab[0] && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }
+        if (P.utab[1] && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
+    }
 
     for (;;) {
         int task = 0;
@@ -815,15 +920,18 @@ __global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restr
         for (int it = 0; it < (1 << 20); it++) {
             if (nH > 0) {
                 int nHn = 0;
-                trace_items<LP>(P, a, S, 0, Hc, nH, Hn, nHn, LW, nL, ST, ostat, level, lum_lost_acc, wc, err);
+                trace_items<LP>(P, a, S, 0, Hc, nH, Hn, nHn, LW, nL, ST, ostat, level, T, lum_lost_acc, wc, err);
                 wave_fence();
                 ListView t = Hc; Hc = Hn; Hn = t;
                 nH = nHn;
             } else if (nL > 0) {
                 int nE = 0;
+                TSTAMP(te0);
                 extract_low<LP>(P, a, LW, nL, Hn, nE, Hc, nH, hkey, hmem, ostat, level, err);
+                TSTAMP(te1);
+                TACC(t_extract, te0, te1);
                 wave_fence();
-                if (nE > 0) trace_items<LP>(P, a, S, 1, Hn, nE, Hc, nH, LW, nL, ST, ostat, level, lum_lost_acc, wc, err);
+                if (nE > 0) trace_items<LP>(P, a, S, 1, Hn, nE, Hc, nH, LW, nL, ST, ostat, level, T, lum_lost_acc, wc, err);
                 wave_fence();
             }
             // define_next_level (rt_routines.f90:2745-2770)
@@ -858,6 +966,14 @@ __global__ void __launch_bounds__(256) rt_stage_kernel(const DevProblem* __restr
         atomicAdd(&P.counters[CNT_UADD], cu);
         atomicAdd(&P.counters[CNT_UREAD], cur);
         atomicAdd(&P.counters[CNT_SCASLOTS], wc.slots);
+#ifdef DRT_PROFILE
+        TSTAMP(tk1);
+        atomicAdd(&P.counters[8], wc.t_setup); atomicAdd(&P.counters[9], wc.t_step); atomicAdd(&P.counters[10], wc.t_flush);
+        atomicAdd(&P.counters[11], wc.t_park); atomicAdd(&P.counters[12], wc.t_next); atomicAdd(&P.counters[13], wc.t_commit);
+        atomicAdd(&P.counters[14], wc.t_extract); atomicAdd(&P.counters[15], tk1 - tk0);
+        atomicAdd(&P.counters[16], wc.n_steps); atomicAdd(&P.counters[17], wc.n_busy_lanes);
+        atomicAdd(&P.counters[18], wc.n_groups); atomicAdd(&P.counters[19], wc.n_deps);
+#endif
         if (err) atomicOr(P.error, err);
     }
 }

@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libdartray_rt.so")
+LIB_PATH = os.environ.get("DRT_LIB", os.path.join(CSRC, "libdartray_rt.so"))
 
 RTT = dict(start=0, precalc_cell=1, precalc_src=2, prep_part2=4, dir_cell=5, i_obs_dir_cell=6, dir_src=7,
            i_obs_dir_src=8, scatt=10, i_obs=11)

@@ -97,8 +97,8 @@ typedef struct drt_counters {
 int drt_create(drt_ctx **out, int device);
 int drt_destroy(drt_ctx *ctx);
 const char *drt_last_error(const drt_ctx *ctx);
-/* arena_bytes: device memory for the per-wave ray queues (0 = default 4 GiB); waves: persistent
- * wavefronts (0 = default). */
+/* arena_bytes: device memory for the per-wave ray queues (0 = default 16 GiB); waves: persistent
+ * wavefronts (0 = as many as the chip keeps resident). */
 int drt_configure(drt_ctx *ctx, size_t arena_bytes, int waves);
 
 /* ---- module state in (grid_initialize, dartray_hub.f90:472-499) ----------------------------------- */

@@ -20,6 +20,16 @@ def stage(name, fn):
     c = g.counters()
     bytes_alg = 40 * c["intersections"] + 8 * c["lambda_deposits"] + 16 * c["u_adds"] + 8 * c["u_reads"] + 16 * c["scaspe_slots"]
     ms = c["kernel_ms"]
+    import ctypes as C
+    if os.environ.get("DRT_PROFILE"):
+        raw = (C.c_ulonglong * 24)()
+        g.L_.drt_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+        g.L_.drt_debug_counters(g.h, raw, 24)
+        tot = max(raw[15], 1)
+        names = ["setup", "step", "flush", "park", "next", "commit", "extract"]
+        print("    phases % of wave time:", {n: round(100 * raw[8 + i] / tot, 1) for i, n in enumerate(names)},
+              "steps", raw[16], "busy lanes/step", round(raw[17] / max(raw[16], 1), 1),
+              "deposits/group", round(raw[19] / max(raw[18], 1), 2))
     print(f"{name:14s} wall {dt*1e3:9.1f} ms kernel {ms:9.2f} ms src {c['sources']:7d} inter {c['intersections']:12d} rays {c['rays']:11d} "
           f"sca {c['scaspe_adds']:12d} | {c['intersections']/max(ms,1e-9)*1e3:.3e} inter/s  {bytes_alg/max(ms,1e-9)*1e3/1e9:8.1f} GB/s alg", flush=True)
 g.rt_prepare("start")
