@@ -1,0 +1,71 @@
+"""CPU-side checks of the boundary: the C-ABI library loads without a GPU and exports every entry
+point include/dartray_rt.h declares; compute entry points fail loudly when no device is present
+(there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dartray_rt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(drt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = ctypes.CDLL(pkg.host.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/dartray_rt.h but not exported"
+    assert set(pkg.host.EXPORTS) <= set(names)
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a gfx950 device the product refuses to run; it never routes through the oracle."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    case = pkg.grids.blob_case(base=(4, 2), max_lvl=2, nlambda=1, blob_r=1.5)
+    with pytest.raises(pkg.DartRayError):
+        pkg.DartRayGPU(case)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dart-ray_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".f90", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_py" not in text and "liboracle" not in text and "dartray_oracle.h" not in text, f
+
+
+def test_grid_layout_invariants(pkg):
+    """Layout contract of smooth_grid_routines.f90:42-58: children contiguous, x fastest; ccindd_to_cc
+    (smooth_grid_routines.f90:820) finds every leaf again from its cindex code (SURVEY 8c iv)."""
+    import numpy as np
+    g = pkg.grids
+    for case in (g.slab_case(max_lvl=3), g.blob_case(base=(3, 3), max_lvl=3, balance=False)):
+        t = case.tree
+        b = t.base
+        bd = (g.basediv(b[0]), g.basediv(b[1]))
+        leaves = np.flatnonzero(t.leaf)
+        for i in leaves[:: max(1, len(leaves) // 300)]:
+            l = 1
+            for lev in range(1, t.lvl[i] + 1):
+                bb = b[0] if lev == 1 else b[1]
+                div = 1 if lev == 1 else bd[0] * bd[1] ** (lev - 2)
+                mask = (bd[0] if lev == 1 else bd[1]) - 1
+                k = ((int(t.cindex[i]) // div) & mask) - 1
+                assert 0 <= k < bb ** 3
+                l = l + k
+                if lev < t.lvl[i]:
+                    assert t.cchild[l] != -1
+                    l = int(t.cchild[l])
+            assert l == i
+        # 2:1 balance across faces when requested
+    t = g.slab_case(max_lvl=4).tree
+    assert t.ncell == 21801 and int(t.leaf.sum()) == 19200

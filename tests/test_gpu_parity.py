@@ -94,3 +94,29 @@ def test_energy_budget_slab(pkg):
     assert 0 < absorbed < lum
     assert lost / lum < 0.01
     g.close()
+
+
+def test_fortran_driver_matches_golden(golden, pkg):
+    """The Fortran host (ISO_C_BINDING facade + dartray_main state machine,
+    dart-ray_amd/fortran/) drives the library through the same stage order as dartray_hub.f90 and
+    reproduces the reference's golden vectors."""
+    import os
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(pkg.__file__), "fortran", "dartray_gpu_driver")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built (amdflang missing)")
+    z, path = golden("blobA")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "f")
+        r = subprocess.run([exe, path, out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got = op.read_ref_output(out + ".out")
+    assert got["iterations"] == int(z["iterations"])
+    for k in ("u_fest", "u_final_dir", "u_final", "i_obs_dir", "i_obs", "sed_dir", "sed"):
+        assert relmax(got[k], z[k]) <= RTOL, k
+    for k in ("lum_lost_dir", "lum_lost"):
+        assert relmax(got[k], z[k]) <= 1e-7, k
+    for il in range(got["L"]):
+        golden_scaspe_check(z, "scaspe_dir", il, got["scaspe_dir"][il], RTOL, "fortran")
+        golden_scaspe_check(z, "scaspe_tot", il, got["scaspe_tot"][il], RTOL, "fortran")
