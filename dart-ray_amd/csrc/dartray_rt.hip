@@ -98,7 +98,9 @@ struct drt_ctx {
     int waves = 0, cap = 0, hcap = 0;
     unsigned long long wave_stride = 0;
     unsigned long long* d_counters = nullptr;
-    int *d_error = nullptr, *d_task = nullptr;
+    int *d_error = nullptr, *d_task = nullptr, *d_spawn_counter = nullptr;
+    char* d_spawn = nullptr;
+    int spawn_cap = 0;
     size_t src_list_cap = 0;
     int* d_dbg = nullptr;
     int dbg_cap = 0;
@@ -189,7 +191,7 @@ extern "C" int drt_destroy(drt_ctx* c)
     free_fields(c);
     void* ptrs[] = {c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
                     c->d_u_final, c->d_lumcell, c->d_p_src_pos, c->d_p_src_lum, c->d_dir_out, c->d_lum_lost, c->d_lum_lost_prev,
-                    c->d_i_obs, c->d_tot, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg};
+                    c->d_i_obs, c->d_tot, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
     if (c->d_dir_out_sc) (void)hipFree(c->d_dir_out_sc);
@@ -766,24 +768,59 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     long long ntasks = (long long)list.size() * (48 / G);
     int blocks = (int)((ntasks + 3) / 4);
     if (blocks > c->waves / 4) blocks = c->waves / 4;
-    if ((rc = carve_arena(c, blocks * 4, a))) return rc;
-    HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+    a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
+    auto launch = [&](int nblocks) {
+        switch (c->LP) {
+        case 1: launch_stage<1>(c, a, nblocks); break;
+        case 2: launch_stage<2>(c, a, nblocks); break;
+        case 4: launch_stage<4>(c, a, nblocks); break;
+        case 8: launch_stage<8>(c, a, nblocks); break;
+        case 16: launch_stage<16>(c, a, nblocks); break;
+        case 32: launch_stage<32>(c, a, nblocks); break;
+        default: launch_stage<64>(c, a, nblocks); break;
+        }
+    };
     HIPCHK(c, hipEventRecord(c->ev0, 0));
-    switch (c->LP) {
-    case 1: launch_stage<1>(c, a, blocks); break;
-    case 2: launch_stage<2>(c, a, blocks); break;
-    case 4: launch_stage<4>(c, a, blocks); break;
-    case 8: launch_stage<8>(c, a, blocks); break;
-    case 16: launch_stage<16>(c, a, blocks); break;
-    case 32: launch_stage<32>(c, a, blocks); break;
-    default: launch_stage<64>(c, a, blocks); break;
+    if (psrc) {
+        // few, deep sources: sub-tree tasks (StageArgs::export_level). Phase 1 exports at most 192 rays per source.
+        const int need = 192 * (int)list.size();
+        if (need > c->spawn_cap || !c->d_spawn) {
+            if (c->d_spawn) (void)hipFree(c->d_spawn);
+            c->spawn_cap = need;
+            HIPCHK(c, hipMalloc((void**)&c->d_spawn, list_bytes(need, c->LP) + 4ull * need));
+        }
+        if (!c->d_spawn_counter) HIPCHK(c, hipMalloc((void**)&c->d_spawn_counter, sizeof(int)));
+        HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
+        a.spawn = c->d_spawn; a.spawn_cap = c->spawn_cap; a.spawn_counter = c->d_spawn_counter;
+        a.export_level = 4;
+        if ((rc = carve_arena(c, blocks * 4, a))) return rc;
+        HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+        launch(blocks);
+        int nspawn = 0;
+        HIPCHK(c, hipMemcpy(&nspawn, c->d_spawn_counter, sizeof(int), hipMemcpyDeviceToHost));
+        c->cnt.launches = 1;
+        if (nspawn > 0) {
+            a.export_level = 0; a.spawn_count = nspawn;
+            long long nt = 4ll * nspawn;
+            int blocks2 = (int)((nt + 3) / 4);
+            if (blocks2 > c->waves / 4) blocks2 = c->waves / 4;
+            if ((rc = carve_arena(c, blocks2 * 4, a))) return rc;
+            HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+            launch(blocks2);
+            c->cnt.launches = 2;
+        }
+    } else {
+        if ((rc = carve_arena(c, blocks * 4, a))) return rc;
+        HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+        launch(blocks);
+        c->cnt.launches = 1;
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, 0));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->cnt.kernel_ms = ms; c->cnt.launches = 1;
+    c->cnt.kernel_ms = ms;
     if ((rc = check_device_error(c))) return rc;
     return pull_counters(c);
 }

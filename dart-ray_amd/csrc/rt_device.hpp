@@ -16,7 +16,7 @@
 enum { RTT_PRECALC_CELL = 1, RTT_PRECALC_SRC = 2, RTT_DIR_CELL = 5, RTT_I_OBS_DIR_CELL = 6, RTT_DIR_SRC = 7,
        RTT_I_OBS_DIR_SRC = 8, RTT_SCATT = 10, RTT_I_OBS = 11 };
 // ray types (ray_list.f90:49-59) and status ids (rt_routines.f90:255-264)
-enum { RAY_HIGH = 0, RAY_LOW = 1, RAY_RECO = 2, RAY_GONE = 3 };
+enum { RAY_HIGH = 0, RAY_LOW = 1, RAY_RECO = 2, RAY_GONE = 3, RAY_ROOT = 4 };  // ROOT: first ray of a sub-tree task
 enum { ST_CONT = 0, ST_GO_HIGH = 1, ST_GONE = 2, ST_GO_LOW = 3, ST_OUT = 4 };
 // error bits
 enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64, ERR_TABLE = 128 };

@@ -22,6 +22,16 @@ struct StageArgs {
     // per-launch carve-up of the ray-queue arena: the fewer waves a stage uses, the deeper its queues
     int cap, hcap;
     unsigned long long wave_stride;
+    // Sub-tree tasks (few, deep sources): phase 1 (export_level = 4) traces the 192 nside-4 rays of a
+    // source and exports the blocked ones; phase 2 (spawn_count > 0) runs one task per child pixel of
+    // an exported ray. Rays at nside <= 8 are never queued for merging (rt_routines.f90:2494), so the
+    // ladders below distinct nside-8 pixels never exchange rays: 768 independent tasks per source
+    // instead of 48 sectors, each performing the reference's operations in the reference's order.
+    int export_level;
+    int spawn_count;
+    char* spawn;        // records: SoA list of spawn_cap rays + int src[spawn_cap]
+    int spawn_cap;
+    int* spawn_counter;
 };
 
 struct ListView {
@@ -304,7 +314,14 @@ __device__ __forceinline__ int deposit(const DevProblem& P, int rt, const SrcInf
 // energy-density increment to u_final(il,cc) in the same instruction. Slot unit vectors of the
 // first two slot tables live in registers (rtab*), so a round touches no memory but the atomics.
 // Weights: w_p = x_p**-1.5 / sum_q x_q**-1.5, x = 1 + g^2 - 2 g cos(angle) (calc_ffn_arr :2252-2260).
-struct RegTabs { double x0, y0, z0, x1, y1, z1; };
+struct RegTabs {
+    double x0, y0, z0, x1, y1, z1;  // slot unit vectors of the first two slot tables, slot = lane
+    // per-wavelength constants of THIS lane's wavelength (lane % LP); a deposit round fetches them from
+    // the depositing lane with readlane instead of loading DevProblem arrays (no memory in the round)
+    int np, tid;
+    double ga, gb, ksca;
+    double* srow;
+};
 #ifdef DRT_NO_ATOMICS  // diagnostic build: keep the values alive, skip the memory operation
 #define FLUSH_ATOMIC(addr, v) asm volatile("" ::"v"(addr), "v"(v))
 #else
@@ -339,12 +356,12 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
         // leaves the wave as one read-modify-write
         unsigned long long grp = __ballot(mine && r.cc == cc_b && il == il_b);
         pend &= ~grp;
-        const int np = P.npix[il_b];
-        double* srow = P.scaspe[il_b] + (unsigned long long)cc_b * np;
+        const int np = bcast_i(T.np, src);
+        const unsigned long long sbase = (unsigned long long)__shfl((long long)T.srow, src, 64);
+        double* srow = (double*)sbase + (unsigned long long)cc_b * np;
         double* uaddr = P.u_final + (unsigned long long)cc_b * P.L + il_b;
-        const int tid = P.tabid[il_b];
-        const double g = P.g[il_b];
-        const double ga = 1.0 + g * g, gb = 2.0 * g;
+        const int tid = bcast_i(T.tid, src);
+        const double ga = bcast_d(T.ga, src), gb = bcast_d(T.gb, src);
         if (np <= 63 && tid <= 1) {
             const double px = tid == 1 ? T.x1 : T.x0, py = tid == 1 ? T.y1 : T.y0, pz = tid == 1 ? T.z1 : T.z0;
             double acc = 0.0, su = 0.0;
@@ -464,7 +481,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                     const int child = (mode == 0) ? (item & 3) : 0;
                     const uint32_t m = in.meta[parent];
                     const int type = META_TYPE(m);
-                    const bool valid = (mode == 0) ? (type == RAY_HIGH || (type == RAY_RECO && child == 0)) : (META_MERGED(m) != 0);
+                    const bool valid = (mode == 0) ? (type == RAY_HIGH || ((type == RAY_RECO || type == RAY_ROOT) && child == 0)) : (META_MERGED(m) != 0);
                     if (valid) {
                         const bool is_reco = (type == RAY_RECO);
                         int ipix_dir = (int)in.ipix[parent];
@@ -491,7 +508,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                                 int k = atomicAdd(&P.dbg[0], 1);
                                 if (k < P.dbg_cap) {
                                     int* d = P.dbg + 1 + 6 * k;
-                                    d[0] = S.nc; d[1] = level; d[2] = ipix_dir; d[3] = cc_old; d[4] = type; d[5] = item;
+                                    d[0] = S.nc; d[1] = level; d[2] = ipix_dir; d[3] = cc_old; d[4] = (type == RAY_ROOT) ? RAY_HIGH : type; d[5] = item;
                                 }
                             }
                         }
@@ -860,13 +877,20 @@ __global__ void __launch_bounds__(256, DRT_MIN_WAVES) rt_stage_kernel(const DevP
     int* ostat = hmem + 4ull * a.hcap + a.cap;  // [cap] status of parked rays / prefix weights
     const int G = a.sectors_per_task;
     const int tasks_per_src = 48 / G;
-    const int ntasks = a.nsources * tasks_per_src;
+    const bool from_spawn = a.spawn_count > 0;
+    const int ntasks = from_spawn ? 4 * a.spawn_count : a.nsources * tasks_per_src;
+    const ListView SP = list_view(a.spawn, 0, a.spawn_cap, LP, 0);
+    const int* spawn_src = (const int*)(a.spawn + list_bytes(a.spawn_cap, LP));
     const int rt = a.rt_type;
     WaveCounters wc = {};
     int err = 0;
     TSTAMP(tk0);
     // slot unit vectors of the first two scaspe slot tables, one slot per lane
-    RegTabs T = {0, 0, 0, 0, 0, 0};
+    RegTabs T = {0, 0, 0, 0, 0, 0, 0, -1, 1.0, 0.0, 0.0, nullptr};
+    if (a.scatter && il < P.L) {
+        const double g = P.g[il];
+        T.np = P.npix[il]; T.tid = P.tabid[il]; T.ga = 1.0 + g * g; T.gb = 2.0 * g; T.ksca = P.ksca[il]; T.srow = P.scaspe[il];
+    }
     if (a.scatter) {
         if (P.utab[0] && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }
         if (P.utab[1] && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
@@ -877,7 +901,7 @@ __global__ void __launch_bounds__(256, DRT_MIN_WAVES) rt_stage_kernel(const DevP
         if (lane == 0) task = atomicAdd(P.task_counter, 1);
         task = first_lane_i(task);
         if (task >= ntasks) break;
-        const int nc = a.src_list[task / tasks_per_src];
+        const int nc = from_spawn ? spawn_src[task >> 2] : a.src_list[task / tasks_per_src];
         const int grp_id = task % tasks_per_src;
         SrcInfo S;
         S.nc = nc;
@@ -904,18 +928,35 @@ __global__ void __launch_bounds__(256, DRT_MIN_WAVES) rt_stage_kernel(const DevP
             if (rt == RTT_PRECALC_SRC || rt == RTT_DIR_SRC) src_lum = P.p_src_lum[(unsigned long long)P.src_cell[nc] * P.L + il];
             else src_lum = P.lumcell[(unsigned long long)nc * P.L + il];
         }
-        for (int s = lane / LP; s < G; s += 64 / LP) {
-            if (il == 0) {
-                Hc.ipix[s] = (uint32_t)(grp_id * G + s);  // idir*4 + idir2 at nside 2
-                Hc.meta[s] = META(1, 0, RAY_HIGH, 0);
-                Hc.cc[s] = nc;
-                Hc.prev[s] = 0.0;
-                Hc.dpl[s] = 0.0;
+        int nH = G, nL = 0, level = 4;
+        if (!from_spawn) {
+            for (int s = lane / LP; s < G; s += 64 / LP) {
+                if (il == 0) {
+                    Hc.ipix[s] = (uint32_t)(grp_id * G + s);  // idir*4 + idir2 at nside 2
+                    Hc.meta[s] = META(1, 0, RAY_HIGH, 0);
+                    Hc.cc[s] = nc;
+                    Hc.prev[s] = 0.0;
+                    Hc.dpl[s] = 0.0;
+                }
+                Hc.lum[(unsigned long long)s * LP + il] = src_lum;
             }
-            Hc.lum[(unsigned long long)s * LP + il] = src_lum;
+        } else {
+            // sub-tree task: child (task & 3) of the exported nside-4 ray, launched at nside 8
+            const int rec = task >> 2;
+            if (lane < LP) {
+                if (il == 0) {
+                    const uint32_t m = SP.meta[rec];
+                    Hc.ipix[0] = 4u * SP.ipix[rec] + (uint32_t)(task & 3);
+                    Hc.meta[0] = META(3, META_ISEL(m), RAY_ROOT, 0);
+                    Hc.cc[0] = SP.cc[rec];
+                    Hc.prev[0] = SP.prev[rec];
+                    Hc.dpl[0] = SP.dpl[rec];
+                }
+                Hc.lum[il] = (il < P.L) ? SP.lum[(unsigned long long)rec * LP + il] : 0.0;
+            }
+            nH = 1; level = 8;
         }
         wave_fence();
-        int nH = G, nL = 0, level = 4;
         double lum_lost_acc = 0.0;
         for (int it = 0; it < (1 << 20); it++) {
             if (nH > 0) {
@@ -924,6 +965,23 @@ __global__ void __launch_bounds__(256, DRT_MIN_WAVES) rt_stage_kernel(const DevP
                 wave_fence();
                 ListView t = Hc; Hc = Hn; Hn = t;
                 nH = nHn;
+                if (level == a.export_level) {
+                    // phase 1 of the sub-tree scheme: hand the blocked nside-4 rays to phase 2
+                    int base = 0;
+                    if (lane == 0 && nH > 0) base = atomicAdd(a.spawn_counter, nH);
+                    base = first_lane_i(base);
+                    int* ssrc = (int*)(a.spawn + list_bytes(a.spawn_cap, LP));
+                    for (int i = lane; i < nH; i += 64) {
+                        const int pos = base + i;
+                        if (pos < a.spawn_cap) {
+                            SP.ipix[pos] = Hc.ipix[i]; SP.meta[pos] = Hc.meta[i]; SP.cc[pos] = Hc.cc[i];
+                            SP.prev[pos] = Hc.prev[i]; SP.dpl[pos] = Hc.dpl[i]; ssrc[pos] = nc;
+                            for (int k = 0; k < P.L; k++) SP.lum[(unsigned long long)pos * LP + k] = Hc.lum[(unsigned long long)i * LP + k];
+                        } else err |= ERR_CAPACITY;
+                    }
+                    nH = 0;
+                    break;
+                }
             } else if (nL > 0) {
                 int nE = 0;
                 TSTAMP(te0);
