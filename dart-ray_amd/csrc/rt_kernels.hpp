@@ -857,13 +857,19 @@ __device__ void extract_low(const DevProblem& P, const StageArgs& a, const ListV
 // ------------------------------------------------------------------------------------------------
 // rt_loop (rt_routines.f90:985-1058) + main_dir_loop (:1343-1467): persistent waves pull tasks.
 // ------------------------------------------------------------------------------------------------
-// 2 waves per SIMD: the queue appends and the f64 atomics leave long in-order vmcnt waits that a
-// second resident wave overlaps (measured +10 % over one wave per SIMD, rocprof: 52 % SQ_WAIT_ANY)
-#ifndef DRT_MIN_WAVES
-#define DRT_MIN_WAVES 2
+// Waves per SIMD the register allocator is told to make room for. The kernel wants ~370 registers;
+// half the time of a lone wave is SQ_WAIT_ANY (dependent tree loads, loads queued behind the f64
+// atomics in vmcnt order), so trading registers for resident waves pays until the spills reach the
+// hot loop. Measured on TRUST-I tau=1 (profiles/r01_occupancy.txt): 64 rays per wave (LP = 1) is best
+// at 2 waves/SIMD (1: 262 ms, 2: 237, 3: 267, 4: 292); 2 rays per wave (LP = 32) at 4
+// (1: 5225 ms, 2: 3140, 3: 2732, 4: 2504, 5: 3557).
+#ifdef DRT_MIN_WAVES
+#define DRT_WAVES_FOR(LP) DRT_MIN_WAVES
+#else
+#define DRT_WAVES_FOR(LP) ((LP) >= 8 ? 4 : (LP) >= 2 ? 3 : 2)
 #endif
 template <int LP>
-__global__ void __launch_bounds__(256, DRT_MIN_WAVES) rt_stage_kernel(const DevProblem* __restrict__ Pp, StageArgs a)
+__global__ void __launch_bounds__(256, DRT_WAVES_FOR(LP)) rt_stage_kernel(const DevProblem* __restrict__ Pp, StageArgs a)
 {
     const DevProblem& P = *Pp;
     const int lane = lane_id();
