@@ -6,7 +6,7 @@
 // performs the stage-end reductions of rt_mpi. No CPU fallback exists: every compute entry point
 // needs a gfx950 device.
 #include "../../include/dartray_rt.h"
-#include "rt_kernels.hpp"
+#include "rt_wide.hpp"
 
 #include <dlfcn.h>
 #include <math.h>
@@ -75,6 +75,7 @@ struct drt_ctx {
     drt_params par{};
     bool have_par = false, have_grid = false, prepared = false, part2 = false;
     int L = 0, LP = 1;
+    bool ray_major = false;  // lane = ray kernel (rt_wide.hpp) instead of lane = (ray, wavelength)
     std::vector<double> ksca, gsca;
     std::vector<int> npix, npix_hp, kp, ik;
     int nuniq = 0;
@@ -282,6 +283,9 @@ extern "C" int drt_set_wavelengths(drt_ctx* c, int32_t lnum, const double* ksca,
     c->L = lnum;
     c->LP = 1;
     while (c->LP < lnum) c->LP <<= 1;
+    // several wavelengths: a lane owns a ray and loops over its wavelengths (DRT_RAY_MAJOR=0 keeps lane = (ray, wavelength))
+    const char* rm = getenv("DRT_RAY_MAJOR");
+    c->ray_major = (lnum >= 2) && !(rm && rm[0] == '0');
     c->ksca.assign(ksca, ksca + lnum);
     c->gsca.assign(gsca, gsca + lnum);
     c->prepared = false;
@@ -455,8 +459,31 @@ template <int LP> static int stage_blocks_per_cu()
     return nb;
 }
 
+#define DRT_LB 4
+static size_t wide_lds_bytes(const drt_ctx* c) { return 4ull * (64ull * c->L + c->LP) * sizeof(double); }
+template <int LP> static int wide_blocks_per_cu(drt_ctx* c)
+{
+    int nb = 0;
+    const size_t lds = wide_lds_bytes(c);
+    if (hipFuncSetAttribute((const void*)rt_stage_wide<LP, DRT_LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide<LP, DRT_LB>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
 static int ensure_arena(drt_ctx* c)
 {
+    if (c->waves <= 0 && c->ray_major) {
+        int nb = 1;
+        switch (c->LP) {
+        case 2: nb = wide_blocks_per_cu<2>(c); break;
+        case 4: nb = wide_blocks_per_cu<4>(c); break;
+        case 8: nb = wide_blocks_per_cu<8>(c); break;
+        case 16: nb = wide_blocks_per_cu<16>(c); break;
+        case 32: nb = wide_blocks_per_cu<32>(c); break;
+        default: nb = wide_blocks_per_cu<64>(c); break;
+        }
+        c->waves = c->ncu * nb * 4;
+    }
     if (c->waves <= 0) {
         // persistent waves: exactly as many as the chip keeps resident (more would only wait for a slot
         // while dividing the queue arena further)
@@ -483,14 +510,14 @@ static int ensure_arena(drt_ctx* c)
 static int carve_arena(drt_ctx* c, int waves, StageArgs& a)
 {
     const unsigned long long per_ray = 4ull * (28 + 8ull * c->LP) + 4ull * 20 + 8 + 16;
-    unsigned long long cap = c->arena_bytes / ((unsigned long long)waves * per_ray);
+    unsigned long long cap = (c->arena_bytes / (unsigned long long)waves - 512ull * c->LP - 272) / per_ray;
     if (cap > (1ull << 22)) cap = 1ull << 22;
     cap = cap / 64 * 64;
     if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, waves);
     int hcap = 64;
     while (hcap < 2 * (int)cap) hcap <<= 1;
     for (;;) {
-        unsigned long long stride = 4ull * list_bytes((int)cap, c->LP) + 20ull * hcap + 8ull * cap;
+        unsigned long long stride = 4ull * list_bytes((int)cap, c->LP) + 20ull * hcap + 8ull * cap + 512ull * c->LP + 16;
         stride = (stride + 255) / 256 * 256;
         if (stride * (unsigned long long)waves <= c->arena_bytes) { a.cap = (int)cap; a.hcap = hcap; a.wave_stride = stride; break; }
         cap -= 64;
@@ -734,6 +761,10 @@ template <int LP> static void launch_stage(drt_ctx* c, const StageArgs& a, int b
 {
     hipLaunchKernelGGL(rt_stage_kernel<LP>, dim3(blocks), dim3(256), 0, 0, c->d_prob, a);
 }
+template <int LP> static void launch_wide(drt_ctx* c, const StageArgs& a, int blocks)
+{
+    hipLaunchKernelGGL((rt_stage_wide<LP, DRT_LB>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
+}
 template <int LP> static void launch_iobs(drt_ctx* c, int rt, int nsrc, int blocks)
 {
     hipLaunchKernelGGL(rt_iobs_kernel<LP>, dim3(blocks), dim3(256), 0, 0, c->d_prob, rt, c->d_src_list, nsrc);
@@ -760,9 +791,11 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     StageArgs a;
     a.rt_type = rt_type; a.nsources = (int)list.size(); a.src_list = c->d_src_list; a.scatter = direct ? 1 : 0;
     const bool psrc = (rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC);
-    int G = (64 / c->LP) / 4;  // 4 children per sector: one task fills the wave's ray slots on its first step
+    int G = (64 / (c->ray_major ? 1 : c->LP)) / 4;  // 4 children per sector: one task fills the wave's ray slots on its first step
     if (G < 1) G = 1;
     if (G > 16) G = 16;
+    // ray-major queues hold lnum doubles per ray: fewer sectors per task keep the longest queue inside the wave's slice
+    if (c->ray_major && c->LP >= 8) G = (c->LP >= 32) ? 2 : (c->LP == 16) ? 4 : 8;
     if (psrc) G = 1;  // few, deep sources: one sector per wave
     a.sectors_per_task = G;
     long long ntasks = (long long)list.size() * (48 / G);
@@ -770,6 +803,17 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if (blocks > c->waves / 4) blocks = c->waves / 4;
     a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
     auto launch = [&](int nblocks) {
+        if (c->ray_major) {
+            switch (c->LP) {
+            case 2: launch_wide<2>(c, a, nblocks); break;
+            case 4: launch_wide<4>(c, a, nblocks); break;
+            case 8: launch_wide<8>(c, a, nblocks); break;
+            case 16: launch_wide<16>(c, a, nblocks); break;
+            case 32: launch_wide<32>(c, a, nblocks); break;
+            default: launch_wide<64>(c, a, nblocks); break;
+            }
+            return;
+        }
         switch (c->LP) {
         case 1: launch_stage<1>(c, a, nblocks); break;
         case 2: launch_stage<2>(c, a, nblocks); break;

@@ -1,0 +1,613 @@
+// dart-ray_amd — the ray-cell stage kernel with lane = ray ("ray-major").
+//
+// rt_stage_kernel<LP> (rt_kernels.hpp) gives every (ray, wavelength) pair a lane: with the 32 wavelengths
+// of a TRUST-I run a wave carries 2 rays, computes each ray's geometry 32 times over, and - because the
+// u_fest pruning of deposit (rt_routines.f90:2470-2480) switches most wavelengths of a ray off early -
+// leaves ~80 % of its lanes idle in the deposit arithmetic (measured: 12 of 64 lanes deposit per step).
+// Here a lane owns a RAY for its whole life, like a thread of the reference does, and the wavelengths are
+// a wave-uniform loop over the ray's iq list (set_iq_list :1860-1893, kept as a 64-bit mask): geometry,
+// queue handling and the tree walk are paid once per ray, wavelengths nobody in the wave has active are
+// skipped, and the 64 rays of a step that cross the same cell still leave the wave as one read-modify-write
+// per (cell, wavelength). Ray intensities live in LDS ([L][64] doubles per wave), the HG normalisation of
+// every (ray, wavelength) in the wave's arena slice.
+//
+// Everything that decides (calc_psel, the beam tests, find_cc_new2, queue order, sibling merging) is the
+// same code as in rt_kernels.hpp; per-wavelength arithmetic is the same sequence of operations.
+#pragma once
+#include "rt_kernels.hpp"
+
+struct SlotVec { double x, y, z; };  // unit vector of scaspe slot `lane` of the first slot table
+
+// value of lane `src` (wave-uniform) of a double, through SGPRs
+__device__ __forceinline__ double readlane_d(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// deposit (rt_routines.f90:2362-2557) for one wavelength of this lane's ray. br: 1 = the ray is narrower
+// than the cell wants (u_fest test, :2455-2490), 2 = deposit u_final + scattered energy, 3 = precalc deposit.
+__device__ __forceinline__ void deposit_lambda(const DevProblem& P, int rt, const SrcInfo& S, int br, int cc, int l, double length,
+                                               double beam_i, double beam_f, double csize_f, double vol_f, double& I,
+                                               double& u_add, double& en_sca, double& lost, bool& alive, WaveCounters& wc)
+{
+    const int nc = S.nc;
+    const unsigned long long idx = (unsigned long long)cc * P.L + l;
+    const double dens = P.dens[idx];
+    double tau_c = dens * length;
+    double ex = exp(-tau_c);
+    double i_av;
+    if (cc != nc) {
+        if (tau_c < P.tau_thin || I == 0) i_av = I;
+        else i_av = I / tau_c * (1 - ex);
+    } else {
+        if (tau_c < P.tau_thin || I == 0) i_av = I;
+        else if (rt != RTT_PRECALC_SRC && rt != RTT_DIR_SRC) {
+            tau_c = dens * S.csize_i;
+            ex = exp(-tau_c);
+            i_av = I / (tau_c * tau_c) * (ex + tau_c - 1);
+        } else {
+            i_av = I / (dens * length) * (1 - ex);
+        }
+    }
+    if (br == 1) {
+        const double u_beam = i_av * csize_f / P.cs / vol_f * S.area_i * beam_f;
+        wc.uread++;
+        if (u_beam < P.en_lim * P.u_fest[idx]) {
+            I = 0;
+            lost = i_av * beam_i * S.csize_i * S.csize_i;
+        }
+        if (I > 0) alive = true;
+        return;
+    }
+    const double v = i_av * length / P.cs / vol_f * S.area_i * beam_i;
+    if (br == 3) {
+        if (v != 0.0) { atomicAdd(&P.u_fest[idx], v); wc.uadd++; }
+    } else {
+        u_add = v;
+        if (v != 0.0) wc.uadd++;
+        const double k = P.ksca[l];
+        if (cc != nc) {
+            if (tau_c > P.tau_thin) en_sca = I * (1.0 - ex) * k * S.area_i * beam_i;
+            else en_sca = I * tau_c * k * S.area_i * beam_i;
+        } else {
+            if (tau_c > P.tau_thin) en_sca = I / (tau_c) * (ex + tau_c - 1) * k * S.area_i * beam_i;
+            else en_sca = I * tau_c / 2 * k * S.area_i * beam_i;
+        }
+    }
+    // update ray_intensity (rt_routines.f90:2543-2555)
+    if (cc != nc) I = I * ex;
+    else if (!(tau_c < P.tau_thin)) I = I / (tau_c) * (1 - ex);
+}
+
+// process_scatt_rad (rt_routines.f90:2638-2726) + the u_final update (:2497-2505) for LB wavelengths
+// l0 .. l0+LB-1 of all rays of this step: rays in the same cell are summed on chip. Lanes 0..np-1 are the
+// scaspe slots, lane 63 carries u_final in the same atomic instruction.
+template <int LB>
+__device__ __forceinline__ void flush_block(const DevProblem& P, int cc, double rnx, double rny, double rnz, const double (&C)[LB],
+                                            const double (&U)[LB], int l0, const SlotVec& T)
+{
+    const int lane = lane_id();
+    bool mine = false;
+#pragma unroll
+    for (int k = 0; k < LB; k++) mine = mine || (C[k] != 0.0 || U[k] != 0.0);
+    unsigned long long pend = __ballot(mine);
+    if (!pend) return;
+    // wave-uniform constants of the LB wavelengths
+    int npk[LB], tidk[LB];
+    double gak[LB], gbk[LB];
+    double* srk[LB];
+#pragma unroll
+    for (int k = 0; k < LB; k++) {
+        const int l = min(l0 + k, P.L - 1);
+        const double g = P.g[l];
+        npk[k] = (l0 + k < P.L) ? P.npix[l] : 0;
+        tidk[k] = P.tabid[l];
+        gak[k] = 1.0 + g * g; gbk[k] = 2.0 * g;
+        srk[k] = P.scaspe[l];
+    }
+    while (pend) {
+        const int src = __ffsll((long long)pend) - 1;
+        const int cc_b = __builtin_amdgcn_readlane(cc, src);
+        const unsigned long long grp = __ballot(mine && cc == cc_b);
+        pend &= ~grp;
+        double acc[LB], su[LB];
+#pragma unroll
+        for (int k = 0; k < LB; k++) { acc[k] = 0.0; su[k] = 0.0; }
+        unsigned long long gm = grp;
+        while (gm) {
+            const int m = __ffsll((long long)gm) - 1;
+            gm &= gm - 1;
+            const double nx = readlane_d(rnx, m), ny = readlane_d(rny, m), nz = readlane_d(rnz, m);
+            const double cs0 = T.x * nx + T.y * ny + T.z * nz;
+#pragma unroll
+            for (int k = 0; k < LB; k++) {
+                const double Cm = readlane_d(C[k], m);
+                su[k] += readlane_d(U[k], m);
+                if (Cm != 0.0) {
+                    if (npk[k] <= 63 && tidk[k] <= 0) {
+                        if (tidk[k] < 0) acc[k] += Cm;  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
+                        else acc[k] += Cm * pow_m1p5(gak[k] - gbk[k] * cs0);
+                    } else {
+                        // slot tables that do not fit the lanes: straight from memory, 64 slots at a time
+                        const int l = l0 + k, np = npk[k];
+                        const double* tab = P.tab[l];
+                        double* srow = srk[k] + (unsigned long long)cc_b * np;
+                        for (int p0 = 0; p0 < np; p0 += 64) {
+                            const int p = p0 + lane;
+                            if (p < np) {
+                                double w = Cm;
+                                if (tab) w = Cm * pow_m1p5(gak[k] - gbk[k] * (tab[p] * nx + tab[np + p] * ny + tab[2 * np + p] * nz));
+                                if (w != 0.0) FLUSH_ATOMIC(&srow[p], w);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LB; k++) {
+            const int np = npk[k];
+            if (np > 0) {
+                const bool fast = (np <= 63 && tidk[k] <= 0);
+                double* uaddr = P.u_final + (unsigned long long)cc_b * P.L + (l0 + k);
+                double* addr = (lane == 63) ? uaddr : (srk[k] + (unsigned long long)cc_b * np + lane);
+                const double v = (lane == 63) ? su[k] : acc[k];
+                if (((fast && lane < np) || lane == 63) && v != 0.0) FLUSH_ATOMIC(addr, v);
+            }
+        }
+    }
+}
+
+// trace_items of rt_kernels.hpp with lane = ray. Ilds: [L][64] LDS intensities of the wave, thg: [L][64]
+// arena, ll: [L] LDS lum_lost of the running task.
+template <int LP, int LB>
+__device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
+                              const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
+                              int* __restrict__ ostat, int level, double* Ilds, double* __restrict__ thg, double* ll,
+                              const SlotVec& T, WaveCounters& wc, int& err)
+{
+    const int lane = lane_id();
+    const int L = P.L;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int rt = a.rt_type;
+    const bool precalc = (rt == RTT_PRECALC_SRC || rt == RTT_PRECALC_CELL);
+    const int n_items = (mode == 0) ? 4 * n_in : n_in;
+    const int nsl = 31 - __clz(level);
+    bool busy = false;
+    int my_item = 0;
+    unsigned long long amask = 0;  // the ray's iq list (sticky, set_iq_list :1860-1893)
+    Ray r;
+    r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
+    r.lam_active = false; r.cx = r.cy = r.cz = 0; r.inc0 = r.inc1 = r.inc2 = 0; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
+    r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
+    long long guard = 0;
+
+    for (int chunk_base = 0; chunk_base < n_items; chunk_base += a.cap) {
+        const int chunk_end = min(n_items, chunk_base + a.cap);
+        for (int i = lane; i < chunk_end - chunk_base; i += 64) ostat[i] = 0;
+        wave_fence();
+        int next_item = chunk_base;
+
+        for (;;) {
+            const unsigned long long busy_b = __ballot(busy);
+            const int n_busy = __popcll(busy_b);
+            const bool more = next_item < chunk_end;
+            if (!more && n_busy == 0) break;
+            if (++guard > (1ll << 26)) { err |= ERR_STEPS; break; }
+
+            TSTAMP(ts0);
+            // ---- refill idle lanes ---------------------------------------------------------------------
+            if (more && (n_busy == 0 || 2 * (64 - n_busy) >= 64)) {
+                const unsigned long long idle = ~busy_b;
+                const int item = next_item + __popcll(idle & below);
+                next_item += __popcll(idle);
+                bool fresh = false;
+                int parent = 0, cc_old = 0;
+                double ct = 1.0, phi = 0.0;
+                if (!busy && item < chunk_end) {
+                    parent = (mode == 0) ? (item >> 2) : item;
+                    const int child = (mode == 0) ? (item & 3) : 0;
+                    const uint32_t m = in.meta[parent];
+                    const int type = META_TYPE(m);
+                    const bool valid = (mode == 0) ? (type == RAY_HIGH || ((type == RAY_RECO || type == RAY_ROOT) && child == 0)) : (META_MERGED(m) != 0);
+                    if (valid) {
+                        const bool is_reco = (type == RAY_RECO);
+                        int ipix_dir = (int)in.ipix[parent];
+                        if (mode == 0 && type == RAY_HIGH) ipix_dir = 4 * ipix_dir + child;
+                        PixDir pd;
+                        if (!pix2ang_nest_sc(P, level, ipix_dir, pd)) err |= ERR_TABLE;
+                        ct = pd.ct; phi = pd.phi;
+                        cc_old = in.cc[parent];
+                        const double prev_ray = in.prev[parent];
+                        const double d0 = pd.st * pd.cp, d1 = pd.st * pd.sp, d2 = pd.ct;  // calc_cproj :1945
+                        bool ok = true;
+                        wc.rays++;  // a call of ray_tracing, including those that return at once (:1656)
+                        if (P.dbg) {
+                            int k = atomicAdd(&P.dbg[0], 1);
+                            if (k < P.dbg_cap) {
+                                int* d = P.dbg + 1 + 6 * k;
+                                d[0] = S.nc; d[1] = level; d[2] = ipix_dir; d[3] = cc_old; d[4] = (type == RAY_ROOT) ? RAY_HIGH : type; d[5] = item;
+                            }
+                        }
+                        if (cc_old == S.nc) {
+                            r.cc = S.nc; r.prev = 0.0; r.isel_old = 0; r.cx = S.px; r.cy = S.py; r.cz = S.pz;
+                            r.cc_new = -1; r.clvl = S.lvl_nc;
+                        } else {
+                            int fr = find_cc_new2(P, S, r, cc_old, d0, d1, d2, prev_ray);
+                            if (fr == 2) err |= ERR_RELOCATE;
+                            if (fr != 0) ok = false;
+                            r.prev = prev_ray; r.cc = r.cc_new; r.isel_old = META_ISEL(m);
+                        }
+                        if (ok) {
+                            r.flag_beam = true;
+                            r.clvl_old = -1;
+                            r.ipix_dir = ipix_dir;
+                            int v;  // incvec (rt_routines.f90:1666-1669)
+                            v = (int)(d0 / P.glepsilon); r.inc0 = max(min(v, 1), -1);
+                            v = (int)(d1 / P.glepsilon); r.inc1 = max(min(v, 1), -1);
+                            v = (int)(d2 / P.glepsilon); r.inc2 = max(min(v, 1), -1);
+                            r.cpi0 = 1 / d0; r.cpi1 = 1 / d1; r.cpi2 = 1 / d2;
+                            double nx = d0, ny = d1, nz = d2;
+                            if (a.scatter && is_reco && level <= 256) {  // "reco" rays read table row 1 (calc_ffn_arr)
+                                PixDir p1;
+                                pix2ang_nest_sc(P, level, 1, p1);
+                                nx = p1.st * p1.cp; ny = p1.st * p1.sp; nz = p1.ct;
+                            }
+                            r.nx = nx; r.ny = ny; r.nz = nz;
+                            busy = true;
+                            fresh = true;
+                            my_item = item - chunk_base;
+                            amask = 0;
+                        }
+                    }
+                }
+                // ---- per wavelength: source luminosity, iq list, HG normalisation (uniform loop) ------
+                if (__ballot(fresh)) {
+                    int kp_prev = -2, ip = 0;
+                    for (int l = 0; l < L; l++) {
+                        if (fresh) {
+                            double src_lum = in.lum[(unsigned long long)parent * LP + l];
+                            if (rt == RTT_SCATT && cc_old == S.nc) {
+                                // assign_src_lum (rt_routines.f90:3043-3071)
+                                const int kp = P.kp[l];
+                                if (kp != kp_prev) { ip = (kp >= 0) ? ang2pix_nest_z(P, 1 << kp, ct, phi) : 0; kp_prev = kp; }
+                                src_lum = P.scaspe_prev[l][(unsigned long long)S.nc * P.npix[l] + ip] * P.npix_hp[l];
+                            }
+                            const double I = src_lum / S.norm;
+                            Ilds[l * 64 + lane] = I;
+                            if (I > 0) amask |= 1ull << l;
+                        }
+                    }
+                    if (a.scatter) {
+                        // calc_ffn_arr (rt_routines.f90:2186-2281): sum over the HEALPix slots of x**-1.5
+                        for (int l = 0; l < L; l++) {
+                            const double* tab = P.tab[l];
+                            double tot = 1.0;
+                            if (tab && fresh && ((amask >> l) & 1ull)) {
+                                const double g = P.g[l];
+                                const int np = P.npix[l], hp = P.npix_hp[l];
+                                const double ga = 1.0 + g * g, gb = 2.0 * g;
+                                tot = 0;
+                                for (int p = 0; p < hp; p++) {
+                                    const double ads = tab[p] * r.nx + tab[np + p] * r.ny + tab[2 * np + p] * r.nz;
+                                    tot += pow_m1p5(ga - gb * ads);
+                                }
+                            }
+                            if (fresh) thg[l * 64 + lane] = tot;
+                        }
+                    }
+                }
+            }
+
+            TSTAMP(ts1);
+            TACC(t_setup, ts0, ts1);
+#ifdef DRT_PROFILE
+            wc.n_steps++; wc.n_busy_lanes += __popcll(__ballot(busy));
+#endif
+            // ---- one ray-cell intersection for every busy lane ---------------------------------------------
+            int status = ST_CONT;
+            double psel = 0.0, length = 0.0;
+            int isel = 0;
+            int br = 0;
+            double beam_i = 0, beam_f = 0, csize_f = 0, vol_f = 0;
+            if (busy) {
+                wc.inter++;
+                calc_psel(P, S, r, psel, isel);
+                length = psel - r.prev;
+                if (fabs(length) < P.len_eps * P.csize_arr[r.clvl]) length = 0;
+                if (length < 0) { err |= ERR_NEG_LENGTH; status = ST_GONE; }
+                if (r.cc != S.nc && r.cc != r.cc_new) r.flag_beam = false;
+                if (length != 0. && status == ST_CONT) {
+                    // deposit, the part that does not depend on the wavelength (rt_routines.f90:2362-2557)
+                    wc.deps++;
+                    wc.lamdep += (unsigned long long)__popcll(amask);
+                    const int npix_beam = 12 * (level * level);
+                    beam_i = 4 * P.pi / npix_beam;
+                    const int lv = P.lvl[r.cc];
+                    csize_f = P.csize_arr[lv]; vol_f = P.cvol_arr[lv];
+                    beam_f = P.carea_arr[lv] / (psel * psel);
+                    const bool narrow = (beam_f / P.bm_par <= beam_i) && !r.flag_beam;
+                    const bool fits = (beam_f / P.bm_par_max < beam_i) || (level <= 8) || r.flag_beam;
+                    if (precalc) {
+                        if (psel > P.rad_lim_ms) status = ST_GONE;
+                        else if (narrow) status = ST_GO_HIGH;
+                        else if (fits) br = 3;
+                        else status = ST_GO_LOW;
+                    } else {
+                        if (narrow) br = 1;
+                        else if (fits) br = 2;
+                        else status = ST_GO_LOW;
+                    }
+                }
+            }
+            TSTAMP(ts2);
+            TACC(t_step, ts1, ts2);
+            // ---- the wavelengths of the step, LB at a time ---------------------------------------------------
+            bool alive = false;
+            if (__ballot(br != 0)) {
+                for (int l0 = 0; l0 < L; l0 += LB) {
+                    const unsigned long long bits = (amask >> l0) & ((1ull << LB) - 1ull);
+                    if (!__ballot(br != 0 && bits != 0ull)) continue;
+                    double C[LB], U[LB];
+#pragma unroll
+                    for (int k = 0; k < LB; k++) {
+                        C[k] = 0.0; U[k] = 0.0;
+                        const int l = l0 + k;
+                        if (br != 0 && ((bits >> k) & 1ull)) {
+                            double I = Ilds[l * 64 + lane];
+                            double e = 0.0, lost = 0.0;
+                            deposit_lambda(P, rt, S, br, r.cc, l, length, beam_i, beam_f, csize_f, vol_f, I, U[k], e, lost, alive, wc);
+                            Ilds[l * 64 + lane] = I;
+                            if (lost != 0.0) atomicAdd(&ll[l], lost);
+                            if (e != 0.0) {
+                                C[k] = e / thg[l * 64 + lane];
+                                wc.sca++;
+                                wc.slots += (unsigned long long)P.npix[l];
+                            }
+                        }
+                    }
+                    if (a.scatter) flush_block<LB>(P, r.cc, r.nx, r.ny, r.nz, C, U, l0, T);
+                }
+            }
+            if (br == 1) {
+                const bool wh = wall_hit(P, rt, r.cc);
+                status = (alive && !wh) ? ST_GO_HIGH : ST_GONE;
+            }
+            TSTAMP(ts3);
+            TACC(t_flush, ts2, ts3);
+
+            // ---- blocked rays are parked at their item's index (add_to_high/low_ray_list, ray_list.f90:463-579)
+            if (busy && (status == ST_GO_HIGH || status == ST_GO_LOW)) {
+                const bool hi = (status == ST_GO_HIGH);
+                const double dpl = r.prev / ((r.isel_old == 1) ? r.cpi0 : (r.isel_old == 2) ? r.cpi1 : r.cpi2);
+                stg.ipix[my_item] = (uint32_t)r.ipix_dir;
+                stg.meta[my_item] = META(nsl, r.isel_old, hi ? RAY_HIGH : RAY_LOW, 0);
+                stg.cc[my_item] = r.cc;
+                // add_to_high zeroes prev/dplane when isel_old == 0 (ray_list.f90:496-503)
+                stg.prev[my_item] = (hi && r.isel_old == 0) ? 0.0 : r.prev;
+                stg.dpl[my_item] = (hi && r.isel_old == 0) ? 0.0 : dpl;
+                ostat[my_item] = hi ? 1 : 2;
+                for (int l = 0; l < L; l++) stg.lum[(unsigned long long)my_item * LP + l] = Ilds[l * 64 + lane] * S.norm;
+            }
+            if (busy && status != ST_CONT) busy = false;
+            TSTAMP(ts4);
+            TACC(t_park, ts3, ts4);
+
+            // ---- next cell --------------------------------------------------------------------------------
+            if (busy) {
+                r.prev = psel;
+                r.isel_old = isel;
+                r.clvl_old = r.clvl;
+                const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
+                const int clvl = r.clvl;
+                bool inside = step_axis(P, r.cx, r.inc0, isel == 1, clvl, psel, r.cpi0, S.sx, c[0]);
+                inside = inside && step_axis(P, r.cy, r.inc1, isel == 2, clvl, psel, r.cpi1, S.sy, c[1]);
+                inside = inside && step_axis(P, r.cz, r.inc2, isel == 3, clvl, psel, r.cpi2, S.sz, c[2]);
+                if (!inside) busy = false;
+                else if (!ccindd_to_cc(P, r.cx, r.cy, r.cz, r.cc, r.clvl)) { err |= ERR_CELL_NOT_FOUND; busy = false; }
+            }
+            TSTAMP(ts5);
+            TACC(t_next, ts4, ts5);
+        }
+        wave_fence();
+        TSTAMP(tc0);
+
+        // ---- commit the parked rays in item order ------------------------------------------------------
+        for (int base = 0; base < chunk_end - chunk_base; base += 64) {
+            const int i = base + lane;
+            const int st = (i < chunk_end - chunk_base) ? ostat[i] : 0;
+            const unsigned long long bh = __ballot(st == 1), bl = __ballot(st == 2);
+            if (!(bh | bl)) continue;
+            const int pos = (st == 1) ? nH + __popcll(bh & lanemask_lt()) : nL + __popcll(bl & lanemask_lt());
+            if (st != 0) {
+                if (pos < a.cap) {
+                    const ListView& o = (st == 1) ? outH : outL;
+                    o.ipix[pos] = stg.ipix[i]; o.meta[pos] = stg.meta[i]; o.cc[pos] = stg.cc[i];
+                    o.prev[pos] = stg.prev[i]; o.dpl[pos] = stg.dpl[i];
+                    for (int k = 0; k < L; k++) o.lum[(unsigned long long)pos * LP + k] = stg.lum[(unsigned long long)i * LP + k];
+                } else err |= ERR_CAPACITY;
+            }
+            nH += __popcll(bh);
+            nL += __popcll(bl);
+        }
+        wave_fence();
+        TSTAMP(tc1);
+        TACC(t_commit, tc0, tc1);
+        if (err & ERR_STEPS) break;
+    }
+}
+
+// rt_loop + main_dir_loop (rt_routines.f90:985-1058, 1343-1467), ray-major. LP is the row stride of the
+// luminosity arrays in the queues (next power of two >= lnum), LB the wavelengths handled per register tile.
+// Dynamic LDS: per wave (64 * L + LP) doubles.
+template <int LP, int LB>
+__global__ void __launch_bounds__(256, 2) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
+{
+    extern __shared__ double lds_w[];
+    const DevProblem& P = *Pp;
+    const int lane = lane_id();
+    const int L = P.L;
+    const int waves_per_block = blockDim.x >> 6;
+    const int wib = threadIdx.x >> 6;
+    const int gwave = blockIdx.x * waves_per_block + wib;
+    double* Ilds = lds_w + (unsigned long long)wib * (64 * L + LP);
+    double* ll = Ilds + 64 * L;
+    char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
+    const unsigned long long lbytes = list_bytes(a.cap, LP);
+    int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]
+    int* hmem = hkey + a.hcap;                  // [4*hcap] sibling slots + [cap] per-entry codes
+    int* ostat = hmem + 4ull * a.hcap + a.cap;  // [cap] status of parked rays / prefix weights
+    double* thg = (double*)(((unsigned long long)(ostat + a.cap) + 15ull) & ~15ull);  // [L][64]
+    const int G = a.sectors_per_task;
+    const int tasks_per_src = 48 / G;
+    const bool from_spawn = a.spawn_count > 0;
+    const int ntasks = from_spawn ? 4 * a.spawn_count : a.nsources * tasks_per_src;
+    const ListView SP = list_view(a.spawn, 0, a.spawn_cap, LP, 0);
+    const int* spawn_src = (const int*)(a.spawn + list_bytes(a.spawn_cap, LP));
+    const int rt = a.rt_type;
+    WaveCounters wc = {};
+    int err = 0;
+    TSTAMP(tk0);
+    SlotVec T = {0, 0, 0};
+    if (a.scatter && P.utab[0] && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x = P.utab[0][lane]; T.y = P.utab[0][n + lane]; T.z = P.utab[0][2 * n + lane]; }
+    if (lane < LP) ll[lane] = 0.0;
+
+    for (;;) {
+        int task = 0;
+        if (lane == 0) task = atomicAdd(P.task_counter, 1);
+        task = first_lane_i(task);
+        if (task >= ntasks) break;
+        const int nc = from_spawn ? spawn_src[task >> 2] : a.src_list[task / tasks_per_src];
+        const int grp_id = task % tasks_per_src;
+        SrcInfo S;
+        S.nc = nc;
+        S.lvl_nc = P.lvl[nc];
+        const bool psrc = (rt == RTT_PRECALC_SRC || rt == RTT_DIR_SRC);
+        if (psrc) {  // calc_src_ccoord (rt_routines.f90:1922-1939)
+            const double* ps = P.p_src_pos + 3ull * (unsigned long long)P.src_cell[nc];
+            S.sx = ps[0]; S.sy = ps[1]; S.sz = ps[2];
+        } else {
+            const double* c = P.ccoord + 3ull * (unsigned long long)nc;
+            S.sx = c[0]; S.sy = c[1]; S.sz = c[2];
+        }
+        S.csize_i = P.csize_arr[S.lvl_nc];
+        S.area_i = P.carea_arr[S.lvl_nc];
+        S.norm = 4 * P.pi * P.csize[nc] * P.csize[nc];
+        S.px = P.cpack[3ull * nc]; S.py = P.cpack[3ull * nc + 1]; S.pz = P.cpack[3ull * nc + 2];
+
+        // create_high_ray_list (ray_list.f90:71-106) for the G sectors of this task
+        ListView Hc = list_view(abase, lbytes, a.cap, LP, 0);
+        ListView Hn = list_view(abase, lbytes, a.cap, LP, 1);
+        const ListView LW = list_view(abase, lbytes, a.cap, LP, 2);
+        const ListView ST = list_view(abase, lbytes, a.cap, LP, 3);
+        int nH = G, nL = 0, level = 4;
+        if (!from_spawn) {
+            if (lane < G) {
+                Hc.ipix[lane] = (uint32_t)(grp_id * G + lane);  // idir*4 + idir2 at nside 2
+                Hc.meta[lane] = META(1, 0, RAY_HIGH, 0);
+                Hc.cc[lane] = nc;
+                Hc.prev[lane] = 0.0;
+                Hc.dpl[lane] = 0.0;
+                for (int l = 0; l < L; l++)
+                    Hc.lum[(unsigned long long)lane * LP + l] = psrc ? P.p_src_lum[(unsigned long long)P.src_cell[nc] * L + l] : P.lumcell[(unsigned long long)nc * L + l];
+            }
+        } else {
+            // sub-tree task: child (task & 3) of the exported nside-4 ray, launched at nside 8
+            const int rec = task >> 2;
+            if (lane == 0) {
+                const uint32_t m = SP.meta[rec];
+                Hc.ipix[0] = 4u * SP.ipix[rec] + (uint32_t)(task & 3);
+                Hc.meta[0] = META(3, META_ISEL(m), RAY_ROOT, 0);
+                Hc.cc[0] = SP.cc[rec];
+                Hc.prev[0] = SP.prev[rec];
+                Hc.dpl[0] = SP.dpl[rec];
+            }
+            if (lane < LP) Hc.lum[lane] = (lane < L) ? SP.lum[(unsigned long long)rec * LP + lane] : 0.0;
+            nH = 1; level = 8;
+        }
+        wave_fence();
+        for (int it = 0; it < (1 << 20); it++) {
+            // one call site for both kinds of pass: mode 0 traces the children of the high queue into the
+            // other high queue, mode 1 the merged rays extract_low left in Hn (its "reco" rays went to Hc)
+            const int mode = (nH > 0) ? 0 : 1;
+            int n_in = nH, n_oh = 0;
+            if (mode == 1) {
+                int nE = 0;
+                TSTAMP(te0);
+                extract_low<LP>(P, a, LW, nL, Hn, nE, Hc, nH, hkey, hmem, ostat, level, err);
+                TSTAMP(te1);
+                TACC(t_extract, te0, te1);
+                wave_fence();
+                n_in = nE; n_oh = nH;
+            }
+            const ListView in = (mode == 0) ? Hc : Hn;
+            const ListView oh = (mode == 0) ? Hn : Hc;
+            if (n_in > 0) trace_items_w<LP, LB>(P, a, S, mode, in, n_in, oh, n_oh, LW, nL, ST, ostat, level, Ilds, thg, ll, T, wc, err);
+            wave_fence();
+            if (mode == 0) {
+                ListView t = Hc; Hc = Hn; Hn = t;
+                if (level == a.export_level) {
+                    // phase 1 of the sub-tree scheme: hand the blocked nside-4 rays to phase 2
+                    nH = n_oh;
+                    int base = 0;
+                    if (lane == 0 && nH > 0) base = atomicAdd(a.spawn_counter, nH);
+                    base = first_lane_i(base);
+                    int* ssrc = (int*)(a.spawn + list_bytes(a.spawn_cap, LP));
+                    for (int i = lane; i < nH; i += 64) {
+                        const int pos = base + i;
+                        if (pos < a.spawn_cap) {
+                            SP.ipix[pos] = Hc.ipix[i]; SP.meta[pos] = Hc.meta[i]; SP.cc[pos] = Hc.cc[i];
+                            SP.prev[pos] = Hc.prev[i]; SP.dpl[pos] = Hc.dpl[i]; ssrc[pos] = nc;
+                            for (int k = 0; k < L; k++) SP.lum[(unsigned long long)pos * LP + k] = Hc.lum[(unsigned long long)i * LP + k];
+                        } else err |= ERR_CAPACITY;
+                    }
+                    nH = 0;
+                    break;
+                }
+            }
+            nH = n_oh;
+            // define_next_level (rt_routines.f90:2745-2770)
+            if (nH > 0) level *= 2;
+            else if (nL > 0) level /= 2;
+            else break;
+            err = wave_or(err);
+            if (level > 8192 || level < 4) err |= ERR_NSIDE;
+            if (err) break;
+        }
+        // lum_lost (rt_routines.f90:1444-1451): one atomic per wavelength
+        if (a.scatter) {
+            wave_fence();
+            if (lane < L) {
+                const double v = ll[lane];
+                if (v != 0.0) { atomicAdd(&P.lum_lost[lane], v); ll[lane] = 0.0; }
+            }
+            wave_fence();
+        }
+        err = wave_or(err);
+        if (err) break;
+    }
+    // counters: one atomic per wave
+    unsigned long long c8[8] = {wc.inter, wc.rays, wc.deps, wc.sca, wc.lamdep, wc.uadd, wc.uread, wc.slots};
+    for (int off = 1; off < 64; off <<= 1)
+        for (int q = 0; q < 8; q++) c8[q] += __shfl_xor(c8[q], off, 64);
+    if (lane == 0) {
+        atomicAdd(&P.counters[CNT_INTERSECTIONS], c8[0]);
+        atomicAdd(&P.counters[CNT_RAYS], c8[1]);
+        atomicAdd(&P.counters[CNT_DEPOSITS], c8[2]);
+        atomicAdd(&P.counters[CNT_SCASPE], c8[3]);
+        atomicAdd(&P.counters[CNT_LAMDEP], c8[4]);
+        atomicAdd(&P.counters[CNT_UADD], c8[5]);
+        atomicAdd(&P.counters[CNT_UREAD], c8[6]);
+        atomicAdd(&P.counters[CNT_SCASLOTS], c8[7]);
+#ifdef DRT_PROFILE
+        TSTAMP(tk1);
+        atomicAdd(&P.counters[8], wc.t_setup); atomicAdd(&P.counters[9], wc.t_step); atomicAdd(&P.counters[10], wc.t_flush);
+        atomicAdd(&P.counters[11], wc.t_park); atomicAdd(&P.counters[12], wc.t_next); atomicAdd(&P.counters[13], wc.t_commit);
+        atomicAdd(&P.counters[14], wc.t_extract); atomicAdd(&P.counters[15], tk1 - tk0);
+        atomicAdd(&P.counters[16], wc.n_steps); atomicAdd(&P.counters[17], wc.n_busy_lanes);
+#endif
+        if (err) atomicOr(P.error, err);
+    }
+}
