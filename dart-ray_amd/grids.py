@@ -507,3 +507,158 @@ def trusti_case(tau_z: float = 1.0, max_lvl: int = 4, wavelengths=None, base=(10
                 p_src_pos=np.array([[0.0, 0.0, 4.0]]), p_src_lum=tab[None, :, 4].copy(), dir_out=dir_out,
                 kp_sca_max=1, rad_lim=0.1, accuracy=0.1, conv_en_lim=0.01, bm_par=10, bm_par_sca=5, bm_par_max=200,
                 wall_on=(False, False, True), wall_coord=wall_coord, dist_obs=10e3, name=name, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE configs 3-5: synthetic counterparts in the reference layout.
+# The reference's own builders and density profiles (create_adap_grid_*.f90, user_routines_*.f90)
+# are out of scope; these generators take the set-up from the shipped input files and fill the
+# grids with analytic profiles, so that every number can be regenerated from this file alone.
+# ----------------------------------------------------------------------------------------------
+
+def _observer_dirs(ndir: int) -> np.ndarray:
+    theta = np.linspace(0.0, PI_REF, ndir) if ndir > 1 else np.array([0.7])
+    phi = np.array([0.37 * j for j in range(ndir)])
+    return np.stack([theta, phi], axis=1) if ndir > 0 else np.zeros((0, 2))
+
+
+def shell_case(max_lvl: int = 3, base=(10, 3), nlambda: int = 4, modelsize: float = 6.0, tau_pc: float = 0.48,
+               semi_axes=(1.09, 2.18, 2.18), half_width: float = 0.10, dtau_max: float = 0.048, ndir: int = 3,
+               lum: float = 4.3e30, name: str = "magtar_shell", **kw) -> Case:
+    """BASELINE config 3, the MAGTAR dust shell (MAGTAR_GRIDS/input_grid_shell.in): base 10,3, max_lvl 3,
+    an ellipsoidal shell of semi-axes (1.09, 2.18, 2.18) pc and normalised half-width 0.10 with
+    extinction 0.48 pc^-1 at the reference wavelength, refined where a cell's optical depth exceeds
+    0.048, one point source at the origin (param_point_sources.dat). `nlambda` wavelengths share the
+    TRUST dust column ratios of TRUSTI_TABLE around 1 um (the MAGTAR opacity file is not restated)."""
+    ax = np.asarray(semi_axes, dtype=np.float64)
+
+    def shell_r(ctr):
+        return np.sqrt(((ctr / ax) ** 2).sum(axis=1))  # 1 on the shell's mid surface
+
+    def refine(level, ctr, size):
+        near = np.abs(shell_r(ctr) - 1.0) < half_width + 0.87 * size / ax.min()
+        return near & (tau_pc * size > dtau_max)
+
+    tree = build_tree(modelsize, base, max_lvl, refine, balance=True)
+    N = tree.ncell
+    idx = [8, 11, 14, 17, 5, 20, 2, 23][:nlambda] if nlambda <= 8 else list(range(nlambda))
+    tab = TRUSTI_TABLE[idx]
+    inside = np.abs(shell_r(tree.ccoord) - 1.0) < half_width
+    dens = np.where(inside, tau_pc, 0.0)[:, None] * tab[None, :, 1]
+    L = tab.shape[0]
+    plum = (lum * tab[:, 4] / tab[:, 4].max())[None, :]
+    return Case(tree=tree, dens=dens, dens_stars=np.zeros((N, L)), ksca_norm=tab[:, 2].copy(), gsca=tab[:, 3].copy(),
+                p_src_pos=np.array([[0.013, -0.021, 0.017]]), p_src_lum=plum, dir_out=_observer_dirs(ndir),
+                kp_sca_max=1, rad_lim=0.1031, accuracy=0.1, conv_en_lim=0.01, bm_par=10, bm_par_sca=5, bm_par_max=200,
+                name=name, **kw)
+
+
+def galaxy_case(max_lvl: int = 3, base=(3, 3), nlambda: int = 3, modelsize: float = 28000.0, hr: float = 4000.0,
+                hz_dust: float = 200.0, hz_stars: float = 350.0, tau_face: float = 1.5, bulge_r: float = 1200.0,
+                dtau_max: float = 0.05, ndir: int = 2, walls: bool = True, name: str = "galaxy", **kw) -> Case:
+    """BASELINE config 4, GALAXY example 1 (GALAXY_GRIDS/input_grid_galaxy_example1.in): modelsize 28 kpc,
+    27-ary tree (base 3,3), every emitting leaf cell is a source (no point sources), bm_par 5,
+    accuracy 0.3, z walls 0.3-0.7 (input_galaxy_example1.in). Dust and stars follow double-exponential
+    discs (scale length hr, scale heights hz_*) plus a Gaussian stellar bulge: an analytic stand-in for
+    user_routines_galaxy.f90. Refinement: cells whose central optical depth exceeds dtau_max."""
+    kdust0 = tau_face / (2.0 * hz_dust)  # face-on optical depth through the centre = tau_face
+
+    def kdust(c):
+        R = np.sqrt(c[:, 0] ** 2 + c[:, 1] ** 2)
+        return kdust0 * np.exp(-R / hr - np.abs(c[:, 2]) / hz_dust)
+
+    def refine(level, ctr, size):
+        # the value at the point of the cell nearest to the mid-plane / axis decides (profiles peak there)
+        near = ctr.copy()
+        near[:, 2] = np.sign(ctr[:, 2]) * np.maximum(np.abs(ctr[:, 2]) - size / 2.0, 0.0)
+        Rn = np.maximum(np.sqrt(ctr[:, 0] ** 2 + ctr[:, 1] ** 2) - 0.71 * size, 0.0)
+        k = kdust0 * np.exp(-Rn / hr - np.abs(near[:, 2]) / hz_dust)
+        return k * size > dtau_max
+
+    tree = build_tree(modelsize, base, max_lvl, refine, balance=True)
+    N = tree.ncell
+    lam_scale = np.array([1.6, 1.0, 0.55, 0.3, 0.18, 0.1][:nlambda])
+    L = lam_scale.shape[0]
+    kd = kdust(tree.ccoord)
+    kd[kd < 1e-4 * kdust0] = 0.0
+    dens = kd[:, None] * lam_scale[None, :]
+    c = tree.ccoord
+    R = np.sqrt(c[:, 0] ** 2 + c[:, 1] ** 2)
+    stars = np.exp(-R / hr - np.abs(c[:, 2]) / hz_stars) + 4.0 * np.exp(-(c ** 2).sum(axis=1) / (2 * bulge_r ** 2))
+    stars[stars < 2e-3] = 0.0
+    dens_stars = (stars * tree.leaf)[:, None] * np.array([0.4, 1.0, 1.3, 1.1, 0.8, 0.5][:L])[None, :] * 1e20
+    wall_coord = np.zeros((3, 2))
+    wall_on = (False, False, False)
+    if walls:
+        wall_on = (False, False, True)
+        wall_coord[2] = np.array([0.3, 0.7]) * modelsize - modelsize / 2.0
+    return Case(tree=tree, dens=dens, dens_stars=dens_stars, ksca_norm=np.array([0.62, 0.58, 0.5, 0.4, 0.3, 0.2][:L]),
+                gsca=np.array([0.55, 0.5, 0.42, 0.3, 0.2, 0.1][:L]), p_src_pos=np.zeros((0, 3)), p_src_lum=np.zeros((0, L)),
+                dir_out=_observer_dirs(ndir), kp_sca_max=1, rad_lim=0.1017, accuracy=0.3, conv_en_lim=0.01, bm_par=5,
+                bm_par_sca=5, bm_par_max=200, wall_on=wall_on, wall_coord=wall_coord, dist_obs=10e6, name=name, **kw)
+
+
+def nbody_case(max_lvl: int = 3, base=(3, 3), nlambda: int = 2, modelsize: float = 40.0, npart: int = 20000,
+               max_part: int = 24, seed: int = 708, ndir: int = 2, name: str = "nbody", **kw) -> Case:
+    """BASELINE config 5, N-body/SPH example 1: the snapshot is not shipped (.gitignore:17-20), so the tree is
+    refined around pseudo-particles drawn from a fixed-seed (PCG64, 708) Plummer sphere + exponential disc:
+    a cell splits while it holds more than `max_part` particles (the criterion of
+    create_adap_grid_Nbody_SPH.f90 restated). Gas particles give the dust density, star particles the
+    emissivity; every emitting leaf is a source. The tree is irregular and unbalanced levels are possible
+    before the 2:1 pass, which is what makes it a different test from the analytic grids."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n1 = npart // 2
+    # Plummer sphere, scale a
+    a = 0.06 * modelsize
+    u = rng.random(n1)
+    r = a / np.sqrt(u ** (-2.0 / 3.0) - 1.0)
+    ct = 2 * rng.random(n1) - 1
+    ph = 2 * np.pi * rng.random(n1)
+    st = np.sqrt(1 - ct * ct)
+    p1 = np.stack([r * st * np.cos(ph), r * st * np.sin(ph), r * ct], axis=1)
+    n2 = npart - n1
+    R = rng.exponential(0.12 * modelsize, n2)
+    ph2 = 2 * np.pi * rng.random(n2)
+    z = rng.laplace(0.0, 0.012 * modelsize, n2)
+    p2 = np.stack([R * np.cos(ph2), R * np.sin(ph2), z], axis=1)
+    part = np.concatenate([p1, p2], axis=0) + np.array([0.011, -0.007, 0.003]) * modelsize
+    part = part[(np.abs(part) < 0.4999 * modelsize).all(axis=1)]
+    is_gas = rng.random(part.shape[0]) < 0.5
+
+    def count(level, ctr, size, sel=None):
+        p = part if sel is None else part[sel]
+        res = int(round(modelsize / size))
+        ip = np.clip(np.floor((p + modelsize / 2.0) / size).astype(np.int64), 0, res - 1)
+        keys = (ip[:, 2] * res + ip[:, 1]) * res + ip[:, 0]
+        ic = np.clip(np.floor((ctr + modelsize / 2.0) / size).astype(np.int64), 0, res - 1)
+        ckeys = (ic[:, 2] * res + ic[:, 1]) * res + ic[:, 0]
+        uk, cnt = np.unique(keys, return_counts=True)
+        pos = np.searchsorted(uk, ckeys)
+        pos = np.clip(pos, 0, max(uk.shape[0] - 1, 0))
+        hit = uk[pos] == ckeys if uk.shape[0] else np.zeros(ckeys.shape[0], dtype=bool)
+        return np.where(hit, cnt[pos] if uk.shape[0] else 0, 0)
+
+    def refine(level, ctr, size):
+        return count(level, ctr, size) > max_part
+
+    tree = build_tree(modelsize, base, max_lvl, refine, balance=True)
+    N = tree.ncell
+    L = nlambda
+    gas = np.zeros(N)
+    stars = np.zeros(N)
+    for l in range(1, tree.max_lvl + 1):
+        m = (tree.lvl == l) & tree.leaf
+        if not m.any():
+            continue
+        size = float(tree.csize[m][0])
+        gas[m] = count(l, tree.ccoord[m], size, is_gas) / size ** 3
+        stars[m] = count(l, tree.ccoord[m], size, ~is_gas) / size ** 3
+    # normalise: optical depth ~1 through the densest cell at the first wavelength
+    kmax = gas.max() if gas.max() > 0 else 1.0
+    smallest = float(tree.csize.min())
+    dens = (gas / kmax * (1.0 / smallest))[:, None] * np.array([1.0, 0.45, 0.2, 0.1][:L])[None, :]
+    dens_stars = stars[:, None] * np.array([1.0, 1.4, 1.1, 0.7][:L])[None, :]
+    return Case(tree=tree, dens=dens, dens_stars=dens_stars, ksca_norm=np.array([0.6, 0.5, 0.4, 0.3][:L]),
+                gsca=np.array([0.5, 0.35, 0.2, 0.0][:L]), p_src_pos=np.zeros((0, 3)), p_src_lum=np.zeros((0, L)),
+                dir_out=_observer_dirs(ndir), kp_sca_max=1, rad_lim=0.1023, accuracy=0.3, conv_en_lim=0.01, bm_par=5,
+                bm_par_sca=5, bm_par_max=200, dist_obs=10e3, name=name, **kw)

@@ -69,3 +69,27 @@ def test_grid_layout_invariants(pkg):
         # 2:1 balance across faces when requested
     t = g.slab_case(max_lvl=4).tree
     assert t.ncell == 21801 and int(t.leaf.sum()) == 19200
+
+
+def test_config_builders_keep_the_reference_layout():
+    """Generators of BASELINE configs 3-5 (dart-ray_amd/grids.py): children contiguous and x-fastest, cindex
+    decodes to the cell, face neighbours within one level, every emitting cell a leaf."""
+    import numpy as np
+    from conftest import load_pkg
+    g = load_pkg().grids
+    for case in (g.shell_case(max_lvl=2, nlambda=2), g.galaxy_case(max_lvl=3), g.nbody_case(max_lvl=3)):
+        t = case.tree
+        N = t.ncell
+        assert t.cchild[0] == 1 and t.lvl[0] == 0
+        par = np.flatnonzero(t.cchild >= 0)
+        for i in par[:: max(1, par.size // 200)]:
+            b = t.base[0] if t.lvl[i] == 0 else t.base[1]
+            kids = np.arange(t.cchild[i], t.cchild[i] + b ** 3)
+            assert kids[-1] < N and (t.lvl[kids] == t.lvl[i] + 1).all()
+            # child k = (iz*b + iy)*b + ix sits at parent corner + (ix+.5, iy+.5, iz+.5) * child size
+            k = np.arange(b ** 3)
+            off = np.stack([k % b, (k // b) % b, k // (b * b)], axis=1)
+            want = t.ccoord[i] - 0.5 * t.csize[i] + (off + 0.5) * t.csize[kids][:, None]
+            assert np.allclose(t.ccoord[kids], want, rtol=0, atol=1e-9 * t.modelsize)
+        assert ((case.dens_stars.sum(axis=1) > 0) <= t.leaf).all()
+        assert np.isfinite(case.dens).all() and (case.dens >= 0).all()

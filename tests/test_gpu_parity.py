@@ -120,3 +120,40 @@ def test_fortran_driver_matches_golden(golden, pkg):
     for il in range(got["L"]):
         golden_scaspe_check(z, "scaspe_dir", il, got["scaspe_dir"][il], RTOL, "fortran")
         golden_scaspe_check(z, "scaspe_tot", il, got["scaspe_tot"][il], RTOL, "fortran")
+
+
+def _baseline_config_cases(grids):
+    """Small versions of BASELINE configs 3-5: MAGTAR shell (base 10,3, one point
+    source), GALAXY example (27-ary tree, every emitting leaf a source, z walls), N-body (irregular tree)."""
+    return {
+        "magtar_shell": lambda: grids.shell_case(max_lvl=2, nlambda=3, ndir=2),
+        "galaxy": lambda: grids.galaxy_case(max_lvl=3, nlambda=3, max_sca_iterations=2),
+        "nbody": lambda: grids.nbody_case(max_lvl=3, nlambda=2, max_sca_iterations=2),
+    }
+
+
+@pytest.mark.parametrize("name", ["magtar_shell", "galaxy", "nbody"])
+def test_gpu_matches_oracle_on_baseline_configs(name, pkg, tmp_path):
+    """The whole dartray_main sequence (precalculation, direct light, scattering iterations, observer
+    passes) on the geometries of BASELINE configs 3-5 at sizes the oracle finishes in seconds: same
+    number of scattering iterations, same fields and SEDs (tolerance 1e-9 of the array maximum; the oracle
+    runs its sources on 8 threads, so its own sums are ordered differently from run to run)."""
+    import os
+    case = _baseline_config_cases(pkg.grids)[name]()
+    path = str(tmp_path / "case.bin")
+    case.write(path)
+    nsrc, ndir = case.p_src_pos.shape[0], case.dir_out.shape[0]
+    o = op.Oracle(path, nsrc=nsrc, ndir=ndir)
+    o.set_parallel(1, 0, min(8, os.cpu_count() or 1))
+    o.run_all(31)
+    g = pkg.DartRayGPU(case)
+    g.run_all(31)
+    assert g.iterations == o.iterations
+    assert relmax(g.u_fest, o.u_fest) <= RTOL
+    assert relmax(g.u_final, o.u_final) <= RTOL
+    assert relmax(g.lum_lost, o.lum_lost) <= 1e-7
+    for il in range(g.L):
+        assert relmax(g.scaspe_tot(il), o.scaspe_tot(il)) <= RTOL
+    assert relmax(g.i_obs, o.i_obs[:ndir]) <= RTOL
+    assert relmax(g.sed(), o.sed()[:ndir]) <= 1e-9   # north_star: 1e-4
+    g.close(); o.close()
