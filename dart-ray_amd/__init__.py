@@ -6,7 +6,7 @@ library `dart-ray_amd/csrc/libdartray_rt.so` (hand-written HIP for gfx950, inclu
 the Fortran facade in `dart-ray_amd/fortran/`; the Python here is the thin host binding used by the
 tests and the benchmark, plus the synthetic-grid generators.
 """
-from . import grids  # noqa: F401
+from . import grids, io  # noqa: F401
 from . import host  # noqa: F401
 from .host import DartRayGPU, DartRayError  # noqa: F401
 
