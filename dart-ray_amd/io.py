@@ -148,3 +148,73 @@ def write_outputs(gpu, label: str, lambdas, out_dir: str, stage: str) -> None:
     write_array(j(filename(label, -1.0, "lum_lost_part2" if part2 else "lum_lost")), "lum_lost", [L], gpu.lum_lost)
     if ndir:
         write_array(j(filename(label, -1.0, "sed_dir" if part2 else "sed")), "sed_arr_dir" if part2 else "sed_arr", [L, ndir], gpu.sed())
+
+
+def write_reference_inputs(case, lambdas, root: str, label: str = "model") -> str:
+    """Write `case` (grids.Case) as the set of files the reference's main programs read (and
+    dart-ray_amd/fortran/dartray_gpu_main reads): <root>/GRIDS/ with the HDF5 main grid, one lambda grid per
+    wavelength, the wavelength list, dir_out and point-source files, an effective-opacity table in the layout
+    of DUST_OPACITY/TRUST/*_Effective.dat and the source spectra table; <root>/RUNS/ for the output; and
+    <root>/input.in with the three namelists. Returns the path of input.in."""
+    lambdas = [float(x) for x in lambdas]
+    L = case.lnum
+    assert len(lambdas) == L and all(b > a for a, b in zip(lambdas, lambdas[1:]))
+    gdir, rdir = os.path.join(root, "GRIDS"), os.path.join(root, "RUNS")
+    os.makedirs(gdir, exist_ok=True)
+    os.makedirs(rdir, exist_ok=True)
+    t = case.tree
+    iref = 0
+    write_main_grid(os.path.join(gdir, f"grid_{label}.h5"), t, case.dens[:, iref], case.dens_stars[:, iref])
+    for il, lam in enumerate(lambdas):
+        write_lambda_grid(os.path.join(gdir, lambda_grid_filename(label, lam)), case.dens[:, il], case.dens_stars[:, il])
+    with open(os.path.join(gdir, "lambda_list.dat"), "w") as f:
+        for lam in lambdas:
+            f.write(f"{lam!r}\n")
+    ndir, nsrc = case.dir_out.shape[0], case.p_src_pos.shape[0]
+    if ndir:
+        with open(os.path.join(gdir, "dir_out.dat"), "w") as f:
+            f.write("theta phi [rad]\n")
+            for th, ph in case.dir_out:
+                f.write(f"{float(th)!r} {float(ph)!r}\n")
+    if nsrc:
+        with open(os.path.join(gdir, "pos_point_sources.dat"), "w") as f:
+            f.write("x y z\n")
+            for p in case.p_src_pos:
+                f.write(" ".join(repr(float(x)) for x in p) + "\n")
+        with open(os.path.join(gdir, "param_point_sources.dat"), "w") as f:
+            f.write("lambda L_nu per source\n")
+            rows = [(0.5 * lambdas[0], case.p_src_lum[:, 0])] + [(lam, case.p_src_lum[:, il]) for il, lam in enumerate(lambdas)]
+            for lam, lum in rows:
+                f.write(f"{lam!r} " + " ".join(repr(float(x)) for x in lum) + "\n")
+    with open(os.path.join(gdir, "opacities_Effective.dat"), "w") as f:
+        f.write("effective quantities written by dart-ray_amd/io.py\n   lam         Cabs          Csca        Tau\n"
+                "   [um]       [cm^2]        [cm^2]      [/N_H]           a           g\n" + "-" * 77 + "\n")
+        K = 1e-21
+        rows = [(0.5 * lambdas[0], case.ksca_norm[0], case.gsca[0])] + [(lam, case.ksca_norm[il], case.gsca[il]) for il, lam in enumerate(lambdas)]
+        for lam, a, g in rows:
+            f.write(f"{lam!r} {(1.0 - float(a)) * K!r} {float(a) * K!r} {K!r} {float(a)!r} {float(g)!r}\n")
+    wc = np.asarray(case.wall_coord, dtype=np.float64)
+    ms = t.modelsize
+    frac = [[float(v) for v in row] for row in (wc + ms / 2.0) / ms]  # set_walls maps fractions of modelsize to model coordinates
+    fl = lambda b: ".TRUE." if b else ".FALSE."
+    inp = os.path.join(root, "input.in")
+    with open(inp, "w") as f:
+        f.write("&dartray_input_strings\n"
+                f"label_model_lambda_grid = '{label}',\nlabel_model_out = '{label}',\ngrid_file = 'grid_{label}.h5',\n"
+                "file_dir_out = 'dir_out.dat',\nfile_p_src = 'pos_point_sources.dat',\nfile_param_src = 'param_point_sources.dat',\n"
+                f"file_lambda_list = 'lambda_list.dat',\ndir_runs = '{rdir}',\ndir_grid = '{gdir}/',\nrt_algorithm = 'main',\n"
+                f"units_lambda = 'um',\ndust_model = 'TRUST',\nfile_av_opacities = '{gdir}/opacities_Effective.dat',\n"
+                "units_csize = 'pc',\nunits_luminosity = 'erg/s/Hz',\ndust_heating_type = 'eff'\n/\n")
+        f.write("&dartray_input_var\n"
+                f"lambda_ref = {lambdas[iref]!r},\nkp_sca_max = {case.kp_sca_max},\nrad_lim = {float(case.rad_lim)!r},\naccuracy = {float(case.accuracy)!r},\n"
+                f"conv_en_lim = {float(case.conv_en_lim)!r},\nbm_par = {case.bm_par},\nbm_par_sca = {case.bm_par_sca},\nbm_par_max = {case.bm_par_max},\n"
+                f"max_lambda_stars = {lambdas[-1] * 1.001!r},\nmin_lambda_dust = 1.,\ndist_obs = {float(case.dist_obs)!r},\nnpixel_maps = 300.,\n"
+                f"x_wall_coord = {frac[0][0]!r}, {frac[0][1]!r},\ny_wall_coord = {frac[1][0]!r}, {frac[1][1]!r},\n"
+                f"z_wall_coord = {frac[2][0]!r}, {frac[2][1]!r},\nmax_sca_iterations = {max(case.max_sca_iterations, 0)}\n/\n")
+        f.write("&dartray_input_logical\n"
+                f"use_lambda_grid = .TRUE.,\nuse_dir_out = {fl(ndir > 0)},\nuse_p_src = {fl(nsrc > 0)},\nprint_output_part1 = .TRUE.,\n"
+                "print_output_part2 = .TRUE.,\nprint_scaspe_part2 = .TRUE.,\nprint_scaspe_tot = .TRUE.,\nprint_sed = .TRUE.,\n"
+                "input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\n"
+                f"x_wall_on = {fl(case.wall_on[0])},\ny_wall_on = {fl(case.wall_on[1])},\nz_wall_on = {fl(case.wall_on[2])},\n"
+                f"limit_scattering_iterations = {fl(case.max_sca_iterations >= 0)}\n/\n")
+    return inp

@@ -157,3 +157,33 @@ def test_gpu_matches_oracle_on_baseline_configs(name, pkg, tmp_path):
     assert relmax(g.i_obs, o.i_obs[:ndir]) <= RTOL
     assert relmax(g.sed(), o.sed()[:ndir]) <= 1e-9   # north_star: 1e-4
     g.close(); o.close()
+
+
+def test_fortran_main_on_reference_style_inputs(pkg, tmp_path):
+    """dartray_gpu_main reads what the reference's programs read (input namelists, wavelength list, HDF5 main
+    and lambda grids, dir_out / point-source files, effective-opacity table) and writes make_output's HDF5 files
+    (io_routines.f90:1743); the fields in those files equal the ones a direct run through the C ABI produces."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "fortran", "dartray_gpu_main")
+    if not os.path.exists(exe) or not os.path.exists(pkg.io.LIB_PATH):
+        pytest.skip("Fortran main program / HDF5 library not built")
+    lambdas = [0.443, 1.0, 2.2]
+    case = pkg.grids.blob_case(base=(4, 2), max_lvl=2, nlambda=3, walls=True, max_sca_iterations=2)
+    inp = pkg.io.write_reference_inputs(case, lambdas, str(tmp_path), label="blob")
+    out = subprocess.run([exe, inp], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    g = pkg.DartRayGPU(case)
+    g.run_all(31)
+    N, nsrc, ndir = g.N, g.nsrc, g.ndir
+    rd = str(tmp_path / "RUNS")
+    f = lambda lam, what: os.path.join(rd, pkg.io.filename("blob", lam, what))
+    for il, lam in enumerate(lambdas):
+        assert relmax(pkg.io.read_array(f(lam, "ufield"), "u_final", [N]), g.u_final[:, il]) <= RTOL
+        assert relmax(pkg.io.read_array(f(lam, "scaspe_tot"), "scaspe_tot", [g.npix[il], N]), g.scaspe_tot(il)) <= RTOL
+        assert pkg.io.read_int(f(lam, "scaspe_tot"), "nside_sca") == 2 ** max(g.kp[il], 0)
+        assert relmax(pkg.io.read_array(f(lam, "i_obs"), "i_obs", [N + nsrc, ndir]), g.i_obs[:, :, il]) <= RTOL
+        assert os.path.exists(f(lam, "u_fest_part1")) and os.path.exists(f(lam, "ufield_part2")) and os.path.exists(f(lam, "scaspe_part2"))
+    assert relmax(pkg.io.read_array(f(-1.0, "lum_lost"), "lum_lost", [g.L]), g.lum_lost) <= 1e-7
+    assert relmax(pkg.io.read_array(f(-1.0, "sed"), "sed_arr", [g.L, ndir]), g.sed()) <= 1e-9
+    g.close()
