@@ -75,7 +75,11 @@ struct drt_ctx {
     drt_params par{};
     bool have_par = false, have_grid = false, prepared = false, part2 = false;
     int L = 0, LP = 1;
-    bool ray_major = false;  // lane = ray kernel (rt_wide.hpp) instead of lane = (ray, wavelength)
+    bool ray_major = false;
+    int G_cell = 0;  // sectors per task that last fitted the queue arena for cell sources (0: not tried yet)
+    std::vector<double*> d_bak_scaspe;  // snapshot of the accumulators of a stage, restored when a launch is repeated
+    double *d_bak_u = nullptr, *d_bak_lost = nullptr;
+    unsigned long long* d_bak_cnt = nullptr;  // lane = ray kernel (rt_wide.hpp) instead of lane = (ray, wavelength)
     std::vector<double> ksca, gsca;
     std::vector<int> npix, npix_hp, kp, ik;
     int nuniq = 0;
@@ -178,6 +182,9 @@ extern "C" int drt_create(drt_ctx** out, int device)
 
 static void free_fields(drt_ctx* c)
 {
+    for (auto p : c->d_bak_scaspe) if (p) (void)hipFree(p);
+    c->d_bak_scaspe.clear();
+    if (c->d_bak_u) { (void)hipFree(c->d_bak_u); c->d_bak_u = nullptr; }
     for (auto p : c->d_scaspe) if (p) (void)hipFree(p);
     for (auto p : c->d_scaspe_prev) if (p) (void)hipFree(p);
     for (auto p : c->d_scaspe_tot) if (p) (void)hipFree(p);
@@ -192,7 +199,8 @@ extern "C" int drt_destroy(drt_ctx* c)
     free_fields(c);
     void* ptrs[] = {c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
                     c->d_u_final, c->d_lumcell, c->d_p_src_pos, c->d_p_src_lum, c->d_dir_out, c->d_lum_lost, c->d_lum_lost_prev,
-                    c->d_i_obs, c->d_tot, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter};
+                    c->d_i_obs, c->d_tot, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter,
+                    c->d_bak_lost, c->d_bak_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
     if (c->d_dir_out_sc) (void)hipFree(c->d_dir_out_sc);
@@ -210,6 +218,7 @@ extern "C" int drt_configure(drt_ctx* c, size_t arena_bytes, int waves)
     if (!c) return DRT_E_ARG;
     if (arena_bytes) c->arena_bytes = arena_bytes;
     if (waves > 0) c->waves = waves;
+    c->G_cell = 0;
     if (c->d_arena) { (void)hipFree(c->d_arena); c->d_arena = nullptr; }
     return DRT_OK;
 }
@@ -794,8 +803,6 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     int G = (64 / (c->ray_major ? 1 : c->LP)) / 4;  // 4 children per sector: one task fills the wave's ray slots on its first step
     if (G < 1) G = 1;
     if (G > 16) G = 16;
-    // ray-major queues hold lnum doubles per ray: fewer sectors per task keep the longest queue inside the wave's slice
-    if (c->ray_major && c->LP >= 8) G = (c->LP >= 32) ? 2 : (c->LP == 16) ? 4 : 8;
     if (psrc) G = 1;  // few, deep sources: one sector per wave
     a.sectors_per_task = G;
     long long ntasks = (long long)list.size() * (48 / G);
@@ -854,10 +861,52 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             c->cnt.launches = 2;
         }
     } else {
-        if ((rc = carve_arena(c, blocks * 4, a))) return rc;
-        HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-        launch(blocks);
-        c->cnt.launches = 1;
+        // Cell sources: G sectors per task. More sectors fill the lanes better but lengthen the queues; how long they
+        // get depends on the grid. The accumulators this stage adds to are snapshotted, and when a queue outgrows its
+        // arena slice the launch is undone and repeated with half the sectors per task (waves stop at the first error).
+        const size_t NL = (size_t)c->N * c->L;
+        if (!c->d_bak_u) HIPCHK(c, hipMalloc((void**)&c->d_bak_u, NL * sizeof(double)));
+        if (!c->d_bak_lost) HIPCHK(c, hipMalloc((void**)&c->d_bak_lost, (size_t)c->L * sizeof(double)));
+        if (!c->d_bak_cnt) HIPCHK(c, hipMalloc((void**)&c->d_bak_cnt, CNT_N * sizeof(unsigned long long)));
+        if (direct && c->d_bak_scaspe.size() != (size_t)c->L) {
+            for (auto p : c->d_bak_scaspe) if (p) (void)hipFree(p);
+            c->d_bak_scaspe.assign(c->L, nullptr);
+            for (int il = 0; il < c->L; il++) HIPCHK(c, hipMalloc((void**)&c->d_bak_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
+        }
+        double* acc_u = precalc ? c->d_u_fest : c->d_u_final;
+        auto copy_state = [&](bool save) -> int {
+            auto cp = [&](void* bak, void* live, size_t bytes) { return save ? hipMemcpyAsync(bak, live, bytes, hipMemcpyDeviceToDevice, 0) : hipMemcpyAsync(live, bak, bytes, hipMemcpyDeviceToDevice, 0); };
+            HIPCHK(c, cp(c->d_bak_u, acc_u, NL * sizeof(double)));
+            HIPCHK(c, cp(c->d_bak_cnt, c->d_counters, CNT_N * sizeof(unsigned long long)));
+            if (direct) {
+                HIPCHK(c, cp(c->d_bak_lost, c->d_lum_lost, (size_t)c->L * sizeof(double)));
+                for (int il = 0; il < c->L; il++) HIPCHK(c, cp(c->d_bak_scaspe[il], c->d_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
+            }
+            return DRT_OK;
+        };
+        int Gtry = c->G_cell > 0 ? std::min(c->G_cell, 16) : G;
+        for (;;) {
+            a.sectors_per_task = Gtry;
+            ntasks = (long long)list.size() * (48 / Gtry);
+            blocks = (int)((ntasks + 3) / 4);
+            if (blocks > c->waves / 4) blocks = c->waves / 4;
+            if ((rc = copy_state(true))) return rc;
+            if ((rc = carve_arena(c, blocks * 4, a))) return rc;
+            HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+            HIPCHK(c, hipEventRecord(c->ev0, 0));
+            launch(blocks);
+            c->cnt.launches++;
+            int e = 0;
+            HIPCHK(c, hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
+            if ((e & ERR_CAPACITY) && !(e & ~ERR_CAPACITY) && Gtry > 1) {
+                HIPCHK(c, hipMemset(c->d_error, 0, sizeof(int)));
+                if ((rc = copy_state(false))) return rc;
+                Gtry /= 2;
+                continue;
+            }
+            break;
+        }
+        c->G_cell = Gtry;
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, 0));

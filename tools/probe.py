@@ -12,7 +12,7 @@ tau = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 max_it = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 wl = list(range(32)) if nl == 32 else ([11] if nl == 1 else list(np.linspace(0, 21, nl).astype(int)))
 t0 = time.time()
-case = pkg.grids.trusti_case(tau_z=tau, max_lvl=max_lvl, wavelengths=wl, max_sca_iterations=max_it)
+case = pkg.grids.trusti_case(tau_z=tau, max_lvl=max_lvl, wavelengths=wl, max_sca_iterations=max_it, top_layers=int(os.environ.get("TOP_LAYERS", "1")))
 print(f"case N={case.tree.ncell} leaves={case.tree.leaf.sum()} L={case.lnum} build {time.time()-t0:.2f}s", flush=True)
 g = pkg.DartRayGPU(case, arena_bytes=int(os.environ.get("ARENA_GB", "16")) << 30)
 def stage(name, fn):
