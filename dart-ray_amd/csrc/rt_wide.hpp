@@ -281,21 +281,58 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                         }
                     }
                     if (a.scatter) {
-                        // calc_ffn_arr (rt_routines.f90:2186-2281): sum over the HEALPix slots of x**-1.5
-                        for (int l = 0; l < L; l++) {
-                            const double* tab = P.tab[l];
-                            double tot = 1.0;
-                            if (tab && fresh && ((amask >> l) & 1ull)) {
-                                const double g = P.g[l];
-                                const int np = P.npix[l], hp = P.npix_hp[l];
-                                const double ga = 1.0 + g * g, gb = 2.0 * g;
-                                tot = 0;
-                                for (int p = 0; p < hp; p++) {
-                                    const double ads = tab[p] * r.nx + tab[np + p] * r.ny + tab[2 * np + p] * r.nz;
-                                    tot += pow_m1p5(ga - gb * ads);
+                        // calc_ffn_arr (rt_routines.f90:2186-2281): sum over the HEALPix slots of x**-1.5. The slot
+                        // cosines do not depend on the wavelength: wavelengths that share a slot table go through the
+                        // slots together, HGB at a time (one dot product per slot instead of one per slot and wavelength).
+                        constexpr int HGB = 8;
+                        for (int l0 = 0; l0 < L; l0 += HGB) {
+                            const unsigned long long want = __ballot(fresh && ((amask >> l0) & ((1ull << HGB) - 1ull)) != 0ull);
+                            const double* tab0 = P.tab[l0];
+                            bool same = true;
+#pragma unroll
+                            for (int k = 0; k < HGB; k++) {
+                                const int l = min(l0 + k, L - 1);
+                                same = same && (P.tab[l] == tab0 || P.tab[l] == nullptr) && (P.tab[l] == nullptr || P.npix_hp[l] == P.npix_hp[l0]);
+                            }
+                            if (!want) {
+                                for (int k = 0; k < HGB && l0 + k < L; k++) if (fresh) thg[(l0 + k) * 64 + lane] = 1.0;
+                            } else if (same && tab0) {
+                                const int np = P.npix[l0], hp = P.npix_hp[l0];
+                                double ga[HGB], gb[HGB], tot[HGB];
+#pragma unroll
+                                for (int k = 0; k < HGB; k++) {
+                                    const double g = P.g[min(l0 + k, L - 1)];
+                                    ga[k] = 1.0 + g * g; gb[k] = 2.0 * g; tot[k] = 0.0;
+                                }
+                                if (fresh) {
+                                    for (int p = 0; p < hp; p++) {
+                                        const double ads = tab0[p] * r.nx + tab0[np + p] * r.ny + tab0[2 * np + p] * r.nz;
+#pragma unroll
+                                        for (int k = 0; k < HGB; k++) tot[k] += pow_m1p5(ga[k] - gb[k] * ads);
+                                    }
+                                }
+#pragma unroll
+                                for (int k = 0; k < HGB; k++) {
+                                    const int l = l0 + k;
+                                    if (l < L && fresh) thg[l * 64 + lane] = (P.tab[l] && ((amask >> l) & 1ull)) ? tot[k] : 1.0;
+                                }
+                            } else {
+                                for (int l = l0; l < min(l0 + HGB, L); l++) {
+                                    const double* tab = P.tab[l];
+                                    double tot = 1.0;
+                                    if (tab && fresh && ((amask >> l) & 1ull)) {
+                                        const double g = P.g[l];
+                                        const int np = P.npix[l], hp = P.npix_hp[l];
+                                        const double ga = 1.0 + g * g, gb = 2.0 * g;
+                                        tot = 0;
+                                        for (int p = 0; p < hp; p++) {
+                                            const double ads = tab[p] * r.nx + tab[np + p] * r.ny + tab[2 * np + p] * r.nz;
+                                            tot += pow_m1p5(ga - gb * ads);
+                                        }
+                                    }
+                                    if (fresh) thg[l * 64 + lane] = tot;
                                 }
                             }
-                            if (fresh) thg[l * 64 + lane] = tot;
                         }
                     }
                 }
