@@ -195,3 +195,35 @@ def test_fortran_main_on_reference_style_inputs(pkg, tmp_path):
     assert relmax(pkg.io.read_array(f(-1.0, "lum_lost"), "lum_lost", [g.L]), g.lum_lost) <= 1e-7
     assert relmax(pkg.io.read_array(f(-1.0, "sed"), "sed_arr", [g.L, ndir]), g.sed()) <= 1e-9
     g.close()
+
+
+@pytest.mark.parametrize("name", ["magtar_shell", "galaxy"])
+def test_full_size_configs_energy_budget(name, pkg):
+    """BASELINE configs 3 and 4 at their full sizes (128 009 and 33 211 cells), where the oracle is too slow to be
+    the checker: size-independent properties instead. Energy absorbed by the dust (sum of u_final * kabs * c * V)
+    is positive and below what the sources emit at every wavelength, shorter wavelengths (more opaque) absorb a
+    larger fraction, the luminosity written off in lum_lost stays small, and a second run reproduces the first
+    to the accuracy of unordered floating-point sums."""
+    g = pkg.grids
+    case = (g.shell_case(max_lvl=3, nlambda=2, max_sca_iterations=1) if name == "magtar_shell"
+            else g.galaxy_case(max_lvl=4, nlambda=3, max_sca_iterations=1))
+    t = case.tree
+    vol = (t.csize ** 3)[:, None]
+    emitted = case.p_src_lum.sum(axis=0) + (case.dens_stars * vol).sum(axis=0)
+
+    def run():
+        gpu = pkg.DartRayGPU(case, arena_bytes=32 << 30)
+        gpu.run_all(11)  # precalculation, direct light, scattering iterations
+        u, lost, it = gpu.u_final, gpu.lum_lost, gpu.iterations
+        gpu.close()
+        return u, lost, it
+
+    u, lost, it = run()
+    assert it >= 1 and np.isfinite(u).all() and (u >= 0).all()
+    absorbed = (u * case.dens * (1.0 - case.ksca_norm)[None, :] * g.CS_PC * vol).sum(axis=0)
+    frac = absorbed / emitted
+    assert (frac > 0).all() and (frac < 1).all()
+    assert (np.diff(frac) < 0).all()  # the wavelength lists of both generators go from opaque to transparent
+    assert (lost / emitted < 0.08).all()
+    u2, lost2, it2 = run()
+    assert it2 == it and relmax(u2, u) <= 1e-11 and relmax(lost2, lost) <= 1e-9
