@@ -430,6 +430,11 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
 // therefore parked in a staging queue at the index of its item and the staging queue is compacted
 // into the high / low queues in item order once the chunk of items is done.
 // ------------------------------------------------------------------------------------------------
+#ifndef DRT_REFILL_QUARTERS
+#define DRT_REFILL_QUARTERS 4  // idle ray slots are refilled when at least this many quarters of the wave wait. Whole
+                               // batches win: rays of a batch stay in phase and leave the wave in fewer atomics (TRUST-I, 1
+                               // wavelength, 21 801 cells: 1: 256 ms, 2: 242, 3: 220, 4: 212)
+#endif
 template <int LP>
 __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in,
                             int n_in, const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
@@ -471,7 +476,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
 
             TSTAMP(ts0);
             // ---- refill idle ray slots -----------------------------------------------------------
-            if (more && (n_busy == 0 || 2 * (R - n_busy) >= R)) {
+            if (more && (n_busy == 0 || 4 * (R - n_busy) >= DRT_REFILL_QUARTERS * R)) {
                 const unsigned long long idle_leaders = (~busy_b) & leaders;
                 const int my_rank = __popcll(idle_leaders & below);
                 const int item = next_item + my_rank;

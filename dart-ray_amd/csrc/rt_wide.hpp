@@ -16,6 +16,11 @@
 #pragma once
 #include "rt_kernels.hpp"
 
+#ifndef DRT_REFILL_IDLE
+#define DRT_REFILL_IDLE 64  // idle lanes are refilled when at least this many of them wait: whole batches keep the rays of a
+                           // batch in phase (siblings cross the same cells in the same step -> more rays per atomic) and cost fewer
+                           // set-up passes; measured 32: 1801 ms, 48: 1758, 64: 1738 (TRUST-I, 32 wavelengths, 21 801 cells)
+#endif
 struct SlotVec { double x, y, z; };  // unit vector of scaspe slot `lane` of the first slot table
 
 // value of lane `src` (wave-uniform) of a double, through SGPRs
@@ -199,7 +204,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 
             TSTAMP(ts0);
             // ---- refill idle lanes ---------------------------------------------------------------------
-            if (more && (n_busy == 0 || 2 * (64 - n_busy) >= 64)) {
+            if (more && (n_busy == 0 || (64 - n_busy) >= DRT_REFILL_IDLE)) {
                 const unsigned long long idle = ~busy_b;
                 const int item = next_item + __popcll(idle & below);
                 next_item += __popcll(idle);
