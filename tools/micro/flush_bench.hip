@@ -6,7 +6,12 @@
 //   1  same without the atomics
 //   2  records staged in LDS, fields fetched with broadcast ds_read
 //   3  like 0 without the per-wavelength zero test
-// usage: flush_bench.bin [run_length]
+//   4  two records per iteration (independent weight chains overlap)
+//   5  one basic block for records whose four wavelengths are all live
+// usage: flush_bench.bin [run_length] [repetitions]
+// MI355X: run length 7: 3.9e9 records/s (4.9e9 without atomics); run length 3: 2.0e9 (4.3e9 without): with few
+// records per cell the loop is bound by the 2.96e9 f64 atomic instructions/s of the chip, and none of the variants
+// 2-5 changes that.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -70,6 +75,28 @@ __global__ void __launch_bounds__(256, 2) k(Rec R, int nrec, double* scaspe, dou
             double acc[LB], su[LB];
 #pragma unroll
             for (int k2 = 0; k2 < LB; k2++) { acc[k2] = 0.0; su[k2] = 0.0; }
+            if (VAR == 4) {
+                // two members per iteration: their weight chains are independent and overlap
+                while (grp) {
+                    const int r0 = __ffsll((long long)grp) - 1;
+                    grp &= grp - 1;
+                    const bool two = grp != 0;
+                    const int r1 = two ? __ffsll((long long)grp) - 1 : r0;
+                    if (two) grp &= grp - 1;
+                    const double ax = readlane_d(hx, r0), ay = readlane_d(hy, r0), az = readlane_d(hz, r0);
+                    const double bx = readlane_d(hx, r1), by = readlane_d(hy, r1), bz = readlane_d(hz, r1);
+                    const double ca = tx * ax + ty * ay + tz * az, cb = tx * bx + ty * by + tz * bz;
+#pragma unroll
+                    for (int k2 = 0; k2 < LB; k2++) {
+                        const double Ca = readlane_d(Cv[k2], r0), Cb = two ? readlane_d(Cv[k2], r1) : 0.0;
+                        su[k2] += readlane_d(Uv[k2], r0) + (two ? readlane_d(Uv[k2], r1) : 0.0);
+                        if (Ca != 0.0 || Cb != 0.0) {
+                            const double wa = pow_m1p5(__builtin_fma(-gbk[k2], ca, gak[k2])), wb = pow_m1p5(__builtin_fma(-gbk[k2], cb, gak[k2]));
+                            acc[k2] = __builtin_fma(Ca, wa, __builtin_fma(Cb, wb, acc[k2]));
+                        }
+                    }
+                }
+            } else
             while (grp) {
                 const int r = __ffsll((long long)grp) - 1;
                 grp &= grp - 1;
@@ -85,6 +112,18 @@ __global__ void __launch_bounds__(256, 2) k(Rec R, int nrec, double* scaspe, dou
                     for (int k2 = 0; k2 < LB; k2++) { Cm[k2] = readlane_d(Cv[k2], r); Um[k2] = readlane_d(Uv[k2], r); }
                 }
                 const double cs0 = tx * nx + ty * ny + tz * nz;
+                if (VAR == 5) {
+                    // all four wavelengths live: one basic block, four independent chains
+                    const bool all4 = Cm[0] != 0.0 && Cm[1] != 0.0 && Cm[2] != 0.0 && Cm[3] != 0.0;
+                    if (all4) {
+                        double w[LB];
+#pragma unroll
+                        for (int k2 = 0; k2 < LB; k2++) w[k2] = pow_m1p5(__builtin_fma(-gbk[k2], cs0, gak[k2]));
+#pragma unroll
+                        for (int k2 = 0; k2 < LB; k2++) { su[k2] += Um[k2]; acc[k2] = __builtin_fma(Cm[k2], w[k2], acc[k2]); }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int k2 = 0; k2 < LB; k2++) {
                     su[k2] += Um[k2];
@@ -141,7 +180,9 @@ int main(int argc, char** argv)
             case 0: hipLaunchKernelGGL(k<0>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
             case 1: hipLaunchKernelGGL(k<1>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
             case 2: hipLaunchKernelGGL(k<2>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
-            default: hipLaunchKernelGGL(k<3>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
+            case 3: hipLaunchKernelGGL(k<3>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
+            case 4: hipLaunchKernelGGL(k<4>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
+            default: hipLaunchKernelGGL(k<5>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -150,6 +191,6 @@ int main(int argc, char** argv)
         printf("variant %d run %d: %8.3f ms  %.3e records/s  %.1f ns per record per wave  (%.0f cycles @2.4GHz)\n", var, RUN, best, (double)N * REPS / best * 1e3,
                best * 1e6 / nrec / REPS, best * 1e6 / nrec / REPS * 2.4);
     };
-    for (int v = 0; v < 4; v++) run(v);
+    for (int v = 0; v < 6; v++) run(v);
     return 0;
 }
