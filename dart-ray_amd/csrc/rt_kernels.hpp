@@ -87,6 +87,35 @@ struct Ray {
     double nx, ny, nz;        // unit vector of the direction used by calc_ads_arr (:2294)
 };
 
+// value of lane `src` (wave-uniform) of a double, through SGPRs
+__device__ __forceinline__ double readlane_d(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// global-address loads and atomics: FLAT instructions (generic pointers) count in lgkmcnt as well as vmcnt, so with
+// flat atomics in flight every LDS or scalar wait also waits for the atomics (see rt_wide.hpp)
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) const double gcdouble;
+__device__ __forceinline__ double gload(const double* p) { return *(gcdouble*)p; }
+__device__ __forceinline__ void gatomic_add(double* p, double v)
+{
+#ifdef DRT_NO_ATOMICS
+    asm volatile("" ::"v"(p), "v"(v));
+#else
+    (void)__hip_atomic_fetch_add((gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 struct WaveCounters { unsigned long long inter, rays, deps, sca, lamdep, uadd, uread, slots;
 #ifdef DRT_PROFILE
     unsigned long long t_setup, t_step, t_flush, t_park, t_next, t_commit, t_extract, t_total, n_steps, n_busy_lanes, n_groups, n_deps;
@@ -321,6 +350,9 @@ struct RegTabs {
     int np, tid;
     double ga, gb, ksca;
     double* srow;
+    // read once per kernel: after an atomic the compiler must assume *Pp changed and would load these again
+    double* u_final;
+    int L;
 };
 #ifdef DRT_NO_ATOMICS  // diagnostic build: keep the values alive, skip the memory operation
 #define FLUSH_ATOMIC(addr, v) asm volatile("" ::"v"(addr), "v"(v))
@@ -339,7 +371,7 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
         unsigned long long q = pend;
         while (q) {
             const int s0 = __ffsll((long long)q) - 1;
-            const int c0 = bcast_i(r.cc, s0);
+            const int c0 = __builtin_amdgcn_readlane(r.cc, s0);
             q &= ~__ballot(r.cc == c0 && (lane % LP) == (s0 % LP));
             wc.n_groups++;
         }
@@ -351,39 +383,39 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
     while (pend) {
         const int src = __ffsll((long long)pend) - 1;
         const int il_b = src % LP;
-        const int cc_b = bcast_i(r.cc, src);
+        const int cc_b = __builtin_amdgcn_readlane(r.cc, src);
         // every lane of this step that deposits into the same (cell, wavelength) is summed on chip and
         // leaves the wave as one read-modify-write
         unsigned long long grp = __ballot(mine && r.cc == cc_b && il == il_b);
         pend &= ~grp;
-        const int np = bcast_i(T.np, src);
-        const unsigned long long sbase = (unsigned long long)__shfl((long long)T.srow, src, 64);
+        const int np = __builtin_amdgcn_readlane(T.np, src);
+        const unsigned long long sbase = readlane_u64((unsigned long long)T.srow, src);
         double* srow = (double*)sbase + (unsigned long long)cc_b * np;
-        double* uaddr = P.u_final + (unsigned long long)cc_b * P.L + il_b;
-        const int tid = bcast_i(T.tid, src);
-        const double ga = bcast_d(T.ga, src), gb = bcast_d(T.gb, src);
+        double* uaddr = T.u_final + (unsigned long long)cc_b * T.L + il_b;
+        const int tid = __builtin_amdgcn_readlane(T.tid, src);
+        const double ga = readlane_d(T.ga, src), gb = readlane_d(T.gb, src);
         if (np <= 63 && tid <= 1) {
             const double px = tid == 1 ? T.x1 : T.x0, py = tid == 1 ? T.y1 : T.y0, pz = tid == 1 ? T.z1 : T.z0;
             double acc = 0.0, su = 0.0;
             while (grp) {
                 const int m = __ffsll((long long)grp) - 1;
                 grp &= grp - 1;
-                const double e_b = bcast_d(e, m);
-                su += bcast_d(u_add, m);
+                const double e_b = readlane_d(e, m);
+                su += readlane_d(u_add, m);
                 if (e_b != 0.0) {
                     wc.sca++;
                     wc.slots += (unsigned long long)np;
                     if (tid < 0) acc += e_b;  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
                     else {
-                        const double nx = bcast_d(r.nx, m), ny = bcast_d(r.ny, m), nz = bcast_d(r.nz, m);
-                        const double C = e_b / bcast_d(r.tot_hg, m);
+                        const double nx = readlane_d(r.nx, m), ny = readlane_d(r.ny, m), nz = readlane_d(r.nz, m);
+                        const double C = e_b / readlane_d(r.tot_hg, m);
                         acc += C * pow_m1p5(ga - gb * (px * nx + py * ny + pz * nz));
                     }
                 }
             }
             double* addr = (lane == 63) ? uaddr : &srow[lane];
             const double v = (lane == 63) ? su : acc;
-            if ((lane < np || lane == 63) && v != 0.0) FLUSH_ATOMIC(addr, v);
+            if ((lane < np || lane == 63) && v != 0.0) gatomic_add(addr, v);
         } else {
             const double* tab = P.tab[il_b];
             double su = 0.0;
@@ -396,23 +428,23 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
                 while (gm) {
                     const int m = __ffsll((long long)gm) - 1;
                     gm &= gm - 1;
-                    const double e_b = bcast_d(e, m);
+                    const double e_b = readlane_d(e, m);
                     if (p0 == 0) {
-                        su += bcast_d(u_add, m);
+                        su += readlane_d(u_add, m);
                         if (e_b != 0.0) { wc.sca++; wc.slots += (unsigned long long)np; }
                     }
                     if (e_b != 0.0) {
                         if (!tab) acc += e_b;
                         else {
-                            const double nx = bcast_d(r.nx, m), ny = bcast_d(r.ny, m), nz = bcast_d(r.nz, m);
-                            const double C = e_b / bcast_d(r.tot_hg, m);
+                            const double nx = readlane_d(r.nx, m), ny = readlane_d(r.ny, m), nz = readlane_d(r.nz, m);
+                            const double C = e_b / readlane_d(r.tot_hg, m);
                             acc += C * pow_m1p5(ga - gb * (px * nx + py * ny + pz * nz));
                         }
                     }
                 }
-                if (p < np && acc != 0.0) FLUSH_ATOMIC(&srow[p], acc);
+                if (p < np && acc != 0.0) gatomic_add(&srow[p], acc);
             }
-            if (lane == 63 && su != 0.0) FLUSH_ATOMIC(uaddr, su);
+            if (lane == 63 && su != 0.0) gatomic_add(uaddr, su);
         }
     }
 }
@@ -897,7 +929,7 @@ __global__ void __launch_bounds__(256, DRT_WAVES_FOR(LP)) rt_stage_kernel(const 
     int err = 0;
     TSTAMP(tk0);
     // slot unit vectors of the first two scaspe slot tables, one slot per lane
-    RegTabs T = {0, 0, 0, 0, 0, 0, 0, -1, 1.0, 0.0, 0.0, nullptr};
+    RegTabs T = {0, 0, 0, 0, 0, 0, 0, -1, 1.0, 0.0, 0.0, nullptr, P.u_final, P.L};
     if (a.scatter && il < P.L) {
         const double g = P.g[il];
         T.np = P.npix[il]; T.tid = P.tabid[il]; T.ga = 1.0 + g * g; T.gb = 2.0 * g; T.ksca = P.ksca[il]; T.srow = P.scaspe[il];

@@ -23,13 +23,6 @@
 #endif
 struct SlotVec { double x, y, z; };  // unit vector of scaspe slot `lane` of the first slot table
 
-// value of lane `src` (wave-uniform) of a double, through SGPRs
-__device__ __forceinline__ double readlane_d(double v, int src)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
 
 // ---- memory discipline of the wavelength loop ---------------------------------------------------------
 // (1) gfx950 counts FLAT instructions (generic pointers) in BOTH vmcnt and lgkmcnt. With flat atomics in flight,
@@ -39,17 +32,6 @@ __device__ __forceinline__ double readlane_d(double v, int src)
 //     again (s_load + wait, four times per cell group in the first version of flush_block). What the loop needs
 //     is read once per kernel: scalars into HotP, the per-wavelength constants into one lane per wavelength
 //     (LaneTab, fetched with readlane: no memory at all).
-typedef __attribute__((address_space(1))) double gdouble;
-typedef __attribute__((address_space(1))) const double gcdouble;
-__device__ __forceinline__ double gload(const double* p) { return *(gcdouble*)p; }
-__device__ __forceinline__ void gatomic_add(double* p, double v)
-{
-#ifdef DRT_NO_ATOMICS
-    asm volatile("" ::"v"(p), "v"(v));
-#else
-    (void)__hip_atomic_fetch_add((gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-}
 struct HotP {
     int L;
     double tau_thin, cs, en_lim;
@@ -61,12 +43,6 @@ struct LaneTab {  // lane l: constants of wavelength l
     int np, tid;
     unsigned long long srow;  // scaspe[l]
 };
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src);
-    return ((unsigned long long)hi << 32) | lo;
-}
 
 // deposit (rt_routines.f90:2362-2557) for one wavelength of this lane's ray. br: 1 = the ray is narrower
 // than the cell wants (u_fest test, :2455-2490), 2 = deposit u_final + scattered energy, 3 = precalc deposit.
