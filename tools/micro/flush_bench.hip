@@ -8,6 +8,7 @@
 //   3  like 0 without the per-wavelength zero test
 //   4  two records per iteration (independent weight chains overlap)
 //   5  one basic block for records whose four wavelengths are all live
+//   6  variant 4 without the atomics
 // usage: flush_bench.bin [run_length] [repetitions]
 // MI355X: run length 7: 3.9e9 records/s (4.9e9 without atomics); run length 3: 2.0e9 (4.3e9 without): with few
 // records per cell the loop is bound by the 2.96e9 f64 atomic instructions/s of the chip, and none of the variants
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) k(Rec R, int nrec, double* scaspe, dou
             double acc[LB], su[LB];
 #pragma unroll
             for (int k2 = 0; k2 < LB; k2++) { acc[k2] = 0.0; su[k2] = 0.0; }
-            if (VAR == 4) {
+            if (VAR == 4 || VAR == 6) {
                 // two members per iteration: their weight chains are independent and overlap
                 while (grp) {
                     const int r0 = __ffsll((long long)grp) - 1;
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(256, 2) k(Rec R, int nrec, double* scaspe, dou
                 double* addr = (lane == 63) ? (u_final + (long long)kk * LB + k2) : (scaspe + ((long long)k2 * ncell + kk) * NP + lane);
                 const double v = (lane == 63) ? su[k2] : acc[k2];
                 if ((lane < NP || lane == 63) && v != 0.0) {
-                    if (VAR == 1) asm volatile("" ::"v"(addr), "v"(v));
+                    if (VAR == 1 || VAR == 6) asm volatile("" ::"v"(addr), "v"(v));
                     else atomicAdd(addr, v);
                 }
             }
@@ -182,7 +183,8 @@ int main(int argc, char** argv)
             case 2: hipLaunchKernelGGL(k<2>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
             case 3: hipLaunchKernelGGL(k<3>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
             case 4: hipLaunchKernelGGL(k<4>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
-            default: hipLaunchKernelGGL(k<5>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
+            case 5: hipLaunchKernelGGL(k<5>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
+            default: hipLaunchKernelGGL(k<6>, dim3(waves / 4), dim3(256), 0, 0, R, nrec, dsc, du, ncell, dtab, 0.5, REPS); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -191,6 +193,6 @@ int main(int argc, char** argv)
         printf("variant %d run %d: %8.3f ms  %.3e records/s  %.1f ns per record per wave  (%.0f cycles @2.4GHz)\n", var, RUN, best, (double)N * REPS / best * 1e3,
                best * 1e6 / nrec / REPS, best * 1e6 / nrec / REPS * 2.4);
     };
-    for (int v = 0; v < 6; v++) run(v);
+    for (int v = 0; v < 7; v++) run(v);
     return 0;
 }
