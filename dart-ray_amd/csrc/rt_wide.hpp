@@ -21,6 +21,9 @@
                            // batch in phase (siblings cross the same cells in the same step -> more rays per atomic) and cost fewer
                            // set-up passes; measured 32: 1801 ms, 48: 1758, 64: 1738 (TRUST-I, 32 wavelengths, 21 801 cells)
 #endif
+#ifndef DRT_WIDE_WAVES
+#define DRT_WIDE_WAVES 2  // waves per SIMD the register allocator provisions for rt_stage_wide
+#endif
 struct SlotVec { double x, y, z; };  // unit vector of scaspe slot `lane` of the first slot table
 
 
@@ -498,7 +501,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 // luminosity arrays in the queues (next power of two >= lnum), LB the wavelengths handled per register tile.
 // Dynamic LDS: per wave (64 * L + LP) doubles.
 template <int LP, int LB>
-__global__ void __launch_bounds__(256, 2) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
+__global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
 {
     extern __shared__ double lds_w[];
     const DevProblem& P = *Pp;
