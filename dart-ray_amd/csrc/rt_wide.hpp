@@ -35,6 +35,10 @@ struct SlotVec { double x, y, z; };  // unit vector of scaspe slot `lane` of the
 //     again (s_load + wait, four times per cell group in the first version of flush_block). What the loop needs
 //     is read once per kernel: scalars into HotP, the per-wavelength constants into one lane per wavelength
 //     (LaneTab, fetched with readlane: no memory at all).
+// LDS pointers carry their address space in the type: as generic pointers they become FLAT accesses wherever the
+// compiler cannot infer the space (e.g. at -O1), and a FLAT f64 atomic on an LDS address raises
+// HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
+typedef __attribute__((address_space(3))) double ldouble;
 struct HotP {
     int L;
     double tau_thin, cs, en_lim;
@@ -186,7 +190,7 @@ __device__ __forceinline__ void flush_block(const DevProblem& P, int cc, double 
 template <int LP, int LB>
 __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
                               const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
-                              int* __restrict__ ostat, int level, double* Ilds, double* __restrict__ thg, double* ll,
+                              int* __restrict__ ostat, int level, ldouble* Ilds, double* __restrict__ thg, ldouble* ll,
                               const SlotVec& T, const HotP& H, const LaneTab& LT, WaveCounters& wc, int& err)
 {
     const int lane = lane_id();
@@ -418,7 +422,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                             double e = 0.0, lost = 0.0;
                             deposit_lambda(H, readlane_d(LT.ksca, l), rt, S, br, r.cc, l, length, beam_i, beam_f, csize_f, vol_f, I, U[k], e, lost, alive, wc);
                             Ilds[l * 64 + lane] = I;
-                            if (lost != 0.0) atomicAdd(&ll[l], lost);
+                            if (lost != 0.0) (void)__hip_atomic_fetch_add(ll + l, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (e != 0.0) {
                                 C[k] = e / gload(thg + l * 64 + lane);
                                 wc.sca++;
@@ -510,8 +514,8 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     const int waves_per_block = blockDim.x >> 6;
     const int wib = threadIdx.x >> 6;
     const int gwave = blockIdx.x * waves_per_block + wib;
-    double* Ilds = lds_w + (unsigned long long)wib * (64 * L + LP);
-    double* ll = Ilds + 64 * L;
+    ldouble* Ilds = (ldouble*)lds_w + wib * (64 * L + LP);
+    ldouble* ll = Ilds + 64 * L;
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
     int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]
