@@ -227,3 +227,43 @@ def test_full_size_configs_energy_budget(name, pkg):
     assert (lost / emitted < 0.08).all()
     u2, lost2, it2 = run()
     assert it2 == it and relmax(u2, u) <= 1e-11 and relmax(lost2, lost) <= 1e-9
+
+
+def test_bench_workload_properties(pkg):
+    """The bench workload itself (BASELINE configs[1]: TRUST-I tau_z = 1, 32 wavelengths, 85 801 cells) through the
+    direct-light stage and one scattering iteration: the oracle would need hours here, so size-independent
+    properties are checked. Every wavelength absorbs a fraction in (0, 1) of what the star emits, the absorbed
+    fraction follows the extinction curve (more opaque -> more absorbed, compared pairwise where the opacity
+    differs by more than a factor of two), the scattering iteration only adds energy, lum_lost stays below the
+    1 % the reference warns about, and the counters of the scattering step equal those of a second, identical step
+    (rays depend only on u_fest and scaspe_prev, both frozen during the step)."""
+    g = pkg.grids
+    case = g.trusti_case(tau_z=1.0, max_lvl=5, wavelengths=list(range(32)), max_sca_iterations=1)
+    t = case.tree
+    assert t.ncell == 85801
+    gpu = pkg.DartRayGPU(case, arena_bytes=96 << 30)
+    gpu.rt_prepare("start")
+    gpu.rt_loop("precalc_cell"); gpu.rt_loop("precalc_src"); gpu.rt_mpi("precalc_src")
+    gpu.rt_prepare("prep_part2")
+    gpu.rt_loop("dir_cell"); gpu.rt_loop("dir_src"); gpu.rt_mpi("dir_src")
+    u_dir = gpu.u_final.copy()
+    assert not gpu.scatt_prepare()
+    gpu.reset_counters(); gpu.rt_loop("scatt"); c1 = gpu.counters()
+    u_sc = gpu.u_final.copy()
+    gpu.reset_counters(); gpu.rt_loop("scatt"); c2 = gpu.counters()
+    for k in ("intersections", "rays", "deposits", "scaspe_adds", "lambda_deposits"):
+        assert c1[k] == c2[k], k
+    lost = gpu.lum_lost.copy()
+    gpu.close()
+    assert np.isfinite(u_sc).all() and (u_sc >= u_dir * (1 - 1e-12)).all()
+    vol = (t.csize ** 3)[:, None]
+    kabs = case.dens * (1.0 - case.ksca_norm)[None, :]
+    emitted = case.p_src_lum.sum(axis=0)
+    frac = (u_dir * kabs * g.CS_PC * vol).sum(axis=0) / emitted
+    assert (frac > 0).all() and (frac < 1).all()
+    kext = g.TRUSTI_TABLE[:, 1] * (1.0 - g.TRUSTI_TABLE[:, 2])  # absorption opacity relative to 1 um
+    for i in range(32):
+        for j in range(32):
+            if kext[i] > 2.0 * kext[j]:
+                assert frac[i] > frac[j], (i, j)
+    assert (lost / emitted < 0.01).all()
