@@ -912,7 +912,8 @@ __global__ void __launch_bounds__(256, DRT_WAVES_FOR(LP)) rt_stage_kernel(const 
     const int lane = lane_id();
     const int il = lane % LP;
     const int waves_per_block = blockDim.x >> 6;
-    const int gwave = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    // wave-uniform by construction, and told so: the arena pointers derived from it live in scalar registers
+    const int gwave = blockIdx.x * waves_per_block + first_lane_i((int)(threadIdx.x >> 6));
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
     int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]

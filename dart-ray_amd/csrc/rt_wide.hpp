@@ -512,7 +512,9 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     const int lane = lane_id();
     const int L = P.L;
     const int waves_per_block = blockDim.x >> 6;
-    const int wib = threadIdx.x >> 6;
+    // wave-uniform by construction, and told so: everything carved from the arena below (queue views, hash, HG table)
+    // then lives in scalar registers instead of 50+ vector registers that are spilled inside divergent code
+    const int wib = first_lane_i((int)(threadIdx.x >> 6));
     const int gwave = blockIdx.x * waves_per_block + wib;
     ldouble* Ilds = (ldouble*)lds_w + wib * (64 * L + LP);
     ldouble* ll = Ilds + 64 * L;

@@ -14,7 +14,7 @@ wl = list(range(32)) if nl == 32 else ([11] if nl == 1 else list(np.linspace(0, 
 t0 = time.time()
 case = pkg.grids.trusti_case(tau_z=tau, max_lvl=max_lvl, wavelengths=wl, max_sca_iterations=max_it, top_layers=int(os.environ.get("TOP_LAYERS", "1")))
 print(f"case N={case.tree.ncell} leaves={case.tree.leaf.sum()} L={case.lnum} build {time.time()-t0:.2f}s", flush=True)
-g = pkg.DartRayGPU(case, arena_bytes=int(os.environ.get("ARENA_GB", "16")) << 30)
+g = pkg.DartRayGPU(case, arena_bytes=int(os.environ.get("ARENA_GB", "16")) << 30, waves=int(os.environ.get("WAVES", "0")))
 def stage(name, fn):
     g.reset_counters(); t = time.time(); fn(); dt = time.time() - t
     c = g.counters()
