@@ -88,10 +88,13 @@ __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 6
 __device__ __forceinline__ double bcast_d(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int first_lane_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// OR over the wave. The result steers wave-uniform control flow, so it is handed back through readfirstlane: a value
+// the compiler can prove uniform lives in a scalar register (a uniform value kept in a vector register can be spilled
+// inside divergent code, where only the active lanes are saved).
 __device__ __forceinline__ int wave_or(int v)
 {
     for (int off = 1; off < 64; off <<= 1) v |= __shfl_xor(v, off, 64);
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -813,7 +813,7 @@ __device__ void extract_low(const DevProblem& P, const StageArgs& a, const ListV
         int incl = v;
         for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
         if (i < nE) wts[i] = run + incl - v;
-        run += __shfl(incl, 63, 64);
+        run += __builtin_amdgcn_readlane(incl, 63);  // scalar: `run` becomes the new queue length
     }
     const int nH_new = run;
     wave_fence();
