@@ -461,6 +461,9 @@ static int upload_problem(drt_ctx* c)
     return DRT_OK;
 }
 
+// one wavelength: grids above ~5e4 cells run the three-waves-per-SIMD build of the kernel (rt_kernels.hpp)
+static bool lp1_three_waves(const drt_ctx* c) { return c->LP == 1 && c->N > 50000 && !getenv("DRT_LP1_TWO_WAVES"); }
+
 template <int LP> static int stage_blocks_per_cu()
 {
     int nb = 0;
@@ -498,7 +501,10 @@ static int ensure_arena(drt_ctx* c)
         // while dividing the queue arena further)
         int nb = 1;
         switch (c->LP) {
-        case 1: nb = stage_blocks_per_cu<1>(); break;
+        case 1:
+            if (lp1_three_waves(c)) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_kernel_1w3, 256, 0) != hipSuccess || nb < 1) nb = 1; }
+            else nb = stage_blocks_per_cu<1>();
+            break;
         case 2: nb = stage_blocks_per_cu<2>(); break;
         case 4: nb = stage_blocks_per_cu<4>(); break;
         case 8: nb = stage_blocks_per_cu<8>(); break;
@@ -822,7 +828,10 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             return;
         }
         switch (c->LP) {
-        case 1: launch_stage<1>(c, a, nblocks); break;
+        case 1:
+            if (lp1_three_waves(c)) hipLaunchKernelGGL(rt_stage_kernel_1w3, dim3(nblocks), dim3(256), 0, 0, c->d_prob, a);
+            else launch_stage<1>(c, a, nblocks);
+            break;
         case 2: launch_stage<2>(c, a, nblocks); break;
         case 4: launch_stage<4>(c, a, nblocks); break;
         case 8: launch_stage<8>(c, a, nblocks); break;

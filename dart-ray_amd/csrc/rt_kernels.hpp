@@ -906,7 +906,7 @@ __device__ void extract_low(const DevProblem& P, const StageArgs& a, const ListV
 #define DRT_WAVES_FOR(LP) ((LP) >= 8 ? 4 : (LP) >= 2 ? 3 : 2)
 #endif
 template <int LP>
-__global__ void __launch_bounds__(256, DRT_WAVES_FOR(LP)) rt_stage_kernel(const DevProblem* __restrict__ Pp, StageArgs a)
+__device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp, const StageArgs& a)
 {
     const DevProblem& P = *Pp;
     const int lane = lane_id();
@@ -1078,6 +1078,18 @@ __global__ void __launch_bounds__(256, DRT_WAVES_FOR(LP)) rt_stage_kernel(const 
 #endif
         if (err) atomicOr(P.error, err);
     }
+}
+
+template <int LP>
+__global__ void __launch_bounds__(256, DRT_WAVES_FOR(LP)) rt_stage_kernel(const DevProblem* __restrict__ Pp, StageArgs a)
+{
+    rt_stage_body<LP>(Pp, a);
+}
+// One wavelength on a large grid: the tree walk misses the caches more often and a third wave per SIMD pays for its
+// spills (85 801 cells: 1465 -> 1205 ms; 21 801 cells: 199 -> 224 ms, so small grids keep two waves).
+__global__ void __launch_bounds__(256, 3) rt_stage_kernel_1w3(const DevProblem* __restrict__ Pp, StageArgs a)
+{
+    rt_stage_body<1>(Pp, a);
 }
 
 // ------------------------------------------------------------------------------------------------
