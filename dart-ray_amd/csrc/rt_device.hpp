@@ -87,7 +87,11 @@ __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << la
 __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ double bcast_d(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int first_lane_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// Orders the global-memory traffic of the lanes of ONE wave: stores of some lanes (queue appends, parked rays, hash
+// slots) are read by other lanes after it. A full fence at agent scope (wait for the stores, write back, invalidate
+// the vector L1): a few microseconds, issued a few times per task. A workgroup-scope fence (waits only) also passed
+// every test, but it relies on this CU's L1 never holding an older copy of a line another lane has just rewritten.
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
 // OR over the wave. The result steers wave-uniform control flow, so it is handed back through readfirstlane: a value
 // the compiler can prove uniform lives in a scalar register (a uniform value kept in a vector register can be spilled
 // inside divergent code, where only the active lanes are saved).
