@@ -769,6 +769,7 @@ static int pull_counters(drt_ctx* c)
     c->cnt.deposits = (int64_t)h[CNT_DEPOSITS]; c->cnt.scaspe_adds = (int64_t)h[CNT_SCASPE];
     c->cnt.lambda_deposits = (int64_t)h[CNT_LAMDEP]; c->cnt.u_adds = (int64_t)h[CNT_UADD];
     c->cnt.u_reads = (int64_t)h[CNT_UREAD]; c->cnt.scaspe_slots = (int64_t)h[CNT_SCASLOTS];
+    c->cnt.atomic_instructions = (int64_t)h[CNT_ATOM]; c->cnt.atomic_lanes = (int64_t)h[CNT_ATOM_LANES];
     return DRT_OK;
 }
 

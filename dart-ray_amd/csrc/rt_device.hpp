@@ -22,7 +22,8 @@ enum { ST_CONT = 0, ST_GO_HIGH = 1, ST_GONE = 2, ST_GO_LOW = 3, ST_OUT = 4 };
 enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64, ERR_TABLE = 128 };
 
 // counters[] slots
-enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7, CNT_N = 24 };
+enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7,
+       CNT_ATOM = 20, CNT_ATOM_LANES = 21, CNT_N = 24 };  // 8..19: phase timers of a -DDRT_PROFILE build
 
 struct DevProblem {
     int N, max_lvl, base0, base1, L, nsrc, ndir, pabs_max;

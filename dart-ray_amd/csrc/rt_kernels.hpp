@@ -117,6 +117,7 @@ __device__ __forceinline__ void gatomic_add(double* p, double v)
 }
 
 struct WaveCounters { unsigned long long inter, rays, deps, sca, lamdep, uadd, uread, slots;
+    unsigned long long atom, atom_lanes;  // wave-uniform: atomic wave-instructions of the deposit loop and their active lanes
 #ifdef DRT_PROFILE
     unsigned long long t_setup, t_step, t_flush, t_park, t_next, t_commit, t_extract, t_total, n_steps, n_busy_lanes, n_groups, n_deps;
 #endif
@@ -415,7 +416,10 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
             }
             double* addr = (lane == 63) ? uaddr : &srow[lane];
             const double v = (lane == 63) ? su : acc;
-            if ((lane < np || lane == 63) && v != 0.0) gatomic_add(addr, v);
+            const bool go = (lane < np || lane == 63) && v != 0.0;
+            const unsigned long long gb_ = __ballot(go);
+            if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
+            if (go) gatomic_add(addr, v);
         } else {
             const double* tab = P.tab[il_b];
             double su = 0.0;
@@ -442,8 +446,12 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
                         }
                     }
                 }
-                if (p < np && acc != 0.0) gatomic_add(&srow[p], acc);
+                const bool go = p < np && acc != 0.0;
+                const unsigned long long gb_ = __ballot(go);
+                if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
+                if (go) gatomic_add(&srow[p], acc);
             }
+            if (__ballot(lane == 63 && su != 0.0)) { wc.atom++; wc.atom_lanes++; }
             if (lane == 63 && su != 0.0) gatomic_add(uaddr, su);
         }
     }
@@ -1068,6 +1076,8 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
         atomicAdd(&P.counters[CNT_UADD], cu);
         atomicAdd(&P.counters[CNT_UREAD], cur);
         atomicAdd(&P.counters[CNT_SCASLOTS], wc.slots);
+        atomicAdd(&P.counters[CNT_ATOM], wc.atom);
+        atomicAdd(&P.counters[CNT_ATOM_LANES], wc.atom_lanes);
 #ifdef DRT_PROFILE
         TSTAMP(tk1);
         atomicAdd(&P.counters[8], wc.t_setup); atomicAdd(&P.counters[9], wc.t_step); atomicAdd(&P.counters[10], wc.t_flush);

@@ -24,7 +24,7 @@
 #ifndef DRT_WIDE_WAVES
 #define DRT_WIDE_WAVES 2  // waves per SIMD the register allocator provisions for rt_stage_wide
 #endif
-struct SlotVec { double x, y, z; };  // unit vector of scaspe slot `lane` of the first slot table
+struct SlotTabs { double x0, y0, z0, x1, y1, z1; };  // unit vectors of scaspe slot `lane` of slot tables 0 and 1 (where they fit the lanes)
 
 
 // ---- memory discipline of the wavelength loop ---------------------------------------------------------
@@ -109,9 +109,16 @@ __device__ __forceinline__ void deposit_lambda(const HotP& P, double ksca_l, int
 // process_scatt_rad (rt_routines.f90:2638-2726) + the u_final update (:2497-2505) for LB wavelengths
 // l0 .. l0+LB-1 of all rays of this step: rays in the same cell are summed on chip. Lanes 0..np-1 are the
 // scaspe slots, lane 63 carries u_final in the same atomic instruction.
+//
+// Slot tables: set_npix_arr (rt_routines.f90:5235-5315) gives a wavelength 12*4^kp HEALPix slots + tot_ndir
+// observer slots. Only kp = 0 and kp = 1 can fit the 63 slot lanes, so the unit vectors of (at most) those two
+// tables live in registers (SlotTabs, slot = lane) and every wavelength using one of them - and the isotropic
+// ones - takes the merged path: ONE f64 atomic instruction per (cell group, wavelength). Tables with more
+// slots than lanes (kp >= 2) go through memory 64 slots at a time, merged over the rays of the group as well.
 template <int LB>
 __device__ __forceinline__ void flush_block(const DevProblem& P, int cc, double rnx, double rny, double rnz, const double (&C)[LB],
-                                            const double (&U)[LB], int l0, const SlotVec& T, const HotP& H, const LaneTab& LT)
+                                            const double (&U)[LB], int l0, const SlotTabs& T, const HotP& H, const LaneTab& LT,
+                                            WaveCounters& wc)
 {
     const int lane = lane_id();
     bool mine = false;
@@ -119,16 +126,21 @@ __device__ __forceinline__ void flush_block(const DevProblem& P, int cc, double 
     for (int k = 0; k < LB; k++) mine = mine || (C[k] != 0.0 || U[k] != 0.0);
     unsigned long long pend = __ballot(mine);
     if (!pend) return;
-    // wave-uniform constants of the LB wavelengths
-    int npk[LB], tidk[LB];
+    // wave-uniform constants of the LB wavelengths. regk: 0 / 1 = register table, -1 = isotropic, 2 = memory table
+    int npk[LB], regk[LB];
     double gak[LB], gbk[LB];
     double* srk[LB];
+    bool need0 = false, need1 = false, big = false;
 #pragma unroll
     for (int k = 0; k < LB; k++) {
         const int l = min(l0 + k, H.L - 1);
         const double g = readlane_d(LT.g, l);
         npk[k] = (l0 + k < H.L) ? __builtin_amdgcn_readlane(LT.np, l) : 0;
-        tidk[k] = __builtin_amdgcn_readlane(LT.tid, l);
+        const int tid = __builtin_amdgcn_readlane(LT.tid, l);
+        regk[k] = (tid < 0) ? -1 : (tid <= 1 && npk[k] <= 63) ? tid : 2;
+        need0 = need0 || (regk[k] == 0 && npk[k] > 0);
+        need1 = need1 || (regk[k] == 1 && npk[k] > 0);
+        big = big || (regk[k] == 2 && npk[k] > 0);
         gak[k] = 1.0 + g * g; gbk[k] = 2.0 * g;
         srk[k] = (double*)readlane_u64(LT.srow, l);
     }
@@ -145,29 +157,16 @@ __device__ __forceinline__ void flush_block(const DevProblem& P, int cc, double 
             const int m = __ffsll((long long)gm) - 1;
             gm &= gm - 1;
             const double nx = readlane_d(rnx, m), ny = readlane_d(rny, m), nz = readlane_d(rnz, m);
-            const double cs0 = T.x * nx + T.y * ny + T.z * nz;
+            double cs0 = 0.0, cs1 = 0.0;
+            if (need0) cs0 = T.x0 * nx + T.y0 * ny + T.z0 * nz;
+            if (need1) cs1 = T.x1 * nx + T.y1 * ny + T.z1 * nz;
 #pragma unroll
             for (int k = 0; k < LB; k++) {
                 const double Cm = readlane_d(C[k], m);
                 su[k] += readlane_d(U[k], m);
-                if (Cm != 0.0) {  // skipping the zeros beats a branch-free loop (1666 vs 1789 ms): 45 % of the entries are zero
-                    if (npk[k] <= 63 && tidk[k] <= 0) {
-                        if (tidk[k] < 0) acc[k] += Cm;  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
-                        else acc[k] += Cm * pow_m1p5(gak[k] - gbk[k] * cs0);
-                    } else {
-                        // slot tables that do not fit the lanes: straight from memory, 64 slots at a time
-                        const int l = l0 + k, np = npk[k];
-                        const double* tab = P.tab[l];
-                        double* srow = srk[k] + (unsigned long long)cc_b * np;
-                        for (int p0 = 0; p0 < np; p0 += 64) {
-                            const int p = p0 + lane;
-                            if (p < np) {
-                                double w = Cm;
-                                if (tab) w = Cm * pow_m1p5(gak[k] - gbk[k] * (tab[p] * nx + tab[np + p] * ny + tab[2 * np + p] * nz));
-                                if (w != 0.0) gatomic_add(&srow[p], w);
-                            }
-                        }
-                    }
+                if (Cm != 0.0 && regk[k] < 2) {  // skipping the zeros beats a branch-free loop (1666 vs 1789 ms): 45 % of the entries are zero
+                    if (regk[k] < 0) acc[k] += Cm;  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
+                    else acc[k] += Cm * pow_m1p5(gak[k] - gbk[k] * (regk[k] == 1 ? cs1 : cs0));
                 }
             }
         }
@@ -175,11 +174,44 @@ __device__ __forceinline__ void flush_block(const DevProblem& P, int cc, double 
         for (int k = 0; k < LB; k++) {
             const int np = npk[k];
             if (np > 0) {
-                const bool fast = (np <= 63 && tidk[k] <= 0);
                 double* uaddr = H.u_final + (unsigned long long)cc_b * H.L + (l0 + k);
                 double* addr = (lane == 63) ? uaddr : (srk[k] + (unsigned long long)cc_b * np + lane);
                 const double v = (lane == 63) ? su[k] : acc[k];
-                if (((fast && lane < np) || lane == 63) && v != 0.0) gatomic_add(addr, v);
+                const bool go = ((regk[k] < 2 && lane < np) || lane == 63) && v != 0.0;
+                const unsigned long long gb_ = __ballot(go);
+                if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
+                if (go) gatomic_add(addr, v);
+            }
+        }
+        if (big) {
+            // slot tables with more slots than lanes: 64 slots at a time from memory, the rays of the group summed per slot
+#pragma unroll
+            for (int k = 0; k < LB; k++) {
+                if (regk[k] == 2 && npk[k] > 0) {
+                    const int np = npk[k];
+                    const double* tab = P.tab[l0 + k];
+                    double* srow = srk[k] + (unsigned long long)cc_b * np;
+                    for (int p0 = 0; p0 < np; p0 += 64) {
+                        const int p = p0 + lane;
+                        double px = 0, py = 0, pz = 0;
+                        if (p < np) { px = gload(tab + p); py = gload(tab + np + p); pz = gload(tab + 2 * np + p); }
+                        double a2 = 0.0;
+                        unsigned long long g2 = grp;
+                        while (g2) {
+                            const int m = __ffsll((long long)g2) - 1;
+                            g2 &= g2 - 1;
+                            const double Cm = readlane_d(C[k], m);
+                            if (Cm != 0.0) {
+                                const double nx = readlane_d(rnx, m), ny = readlane_d(rny, m), nz = readlane_d(rnz, m);
+                                a2 += Cm * pow_m1p5(gak[k] - gbk[k] * (px * nx + py * ny + pz * nz));
+                            }
+                        }
+                        const bool go = (p < np) && a2 != 0.0;
+                        const unsigned long long gb_ = __ballot(go);
+                        if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
+                        if (go) gatomic_add(&srow[p], a2);
+                    }
+                }
             }
         }
     }
@@ -191,7 +223,7 @@ template <int LP, int LB>
 __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
                               const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
                               int* __restrict__ ostat, int level, ldouble* Ilds, double* __restrict__ thg, ldouble* ll,
-                              const SlotVec& T, const HotP& H, const LaneTab& LT, WaveCounters& wc, int& err)
+                              const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc, int& err)
 {
     const int lane = lane_id();
     const int L = H.L;
@@ -430,7 +462,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                             }
                         }
                     }
-                    if (a.scatter) flush_block<LB>(P, r.cc, r.nx, r.ny, r.nz, C, U, l0, T, H, LT);
+                    if (a.scatter) flush_block<LB>(P, r.cc, r.nx, r.ny, r.nz, C, U, l0, T, H, LT, wc);
                 }
             }
             if (br == 1) {
@@ -539,8 +571,11 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     H.dens = P.dens; H.u_fest_r = P.u_fest; H.u_fest = P.u_fest; H.u_final = P.u_final;
     LaneTab LT = {0.0, 0.0, 0, -1, 0ull};
     if (lane < P.L) { LT.g = P.g[lane]; LT.ksca = P.ksca[lane]; LT.np = P.npix[lane]; LT.tid = P.tabid[lane]; LT.srow = (unsigned long long)P.scaspe[lane]; }
-    SlotVec T = {0, 0, 0};
-    if (a.scatter && P.utab[0] && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x = P.utab[0][lane]; T.y = P.utab[0][n + lane]; T.z = P.utab[0][2 * n + lane]; }
+    SlotTabs T = {0, 0, 0, 0, 0, 0};
+    if (a.scatter) {
+        if (P.utab[0] && P.utab_np[0] <= 63 && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }
+        if (P.utab[1] && P.utab_np[1] <= 63 && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
+    }
     if (lane < LP) ll[lane] = 0.0;
 
     for (;;) {
@@ -670,6 +705,8 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         atomicAdd(&P.counters[CNT_UADD], c8[5]);
         atomicAdd(&P.counters[CNT_UREAD], c8[6]);
         atomicAdd(&P.counters[CNT_SCASLOTS], c8[7]);
+        atomicAdd(&P.counters[CNT_ATOM], wc.atom);
+        atomicAdd(&P.counters[CNT_ATOM_LANES], wc.atom_lanes);
 #ifdef DRT_PROFILE
         TSTAMP(tk1);
         atomicAdd(&P.counters[8], wc.t_setup); atomicAdd(&P.counters[9], wc.t_step); atomicAdd(&P.counters[10], wc.t_flush);

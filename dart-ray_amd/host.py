@@ -38,7 +38,8 @@ class Params(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("intersections", C.c_int64), ("rays", C.c_int64), ("deposits", C.c_int64), ("scaspe_adds", C.c_int64),
                 ("lambda_deposits", C.c_int64), ("u_adds", C.c_int64), ("u_reads", C.c_int64), ("scaspe_slots", C.c_int64),
-                ("sources", C.c_int64), ("kernel_ms", C.c_double), ("launches", C.c_int64)]
+                ("sources", C.c_int64), ("kernel_ms", C.c_double), ("launches", C.c_int64),
+                ("atomic_instructions", C.c_int64), ("atomic_lanes", C.c_int64)]
 
 
 EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_set_grid", "drt_set_params",
@@ -50,7 +51,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
 
 def build(force: bool = False) -> str:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("dartray_rt.hip", "rt_kernels.hpp", "rt_device.hpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("dartray_rt.hip", "rt_kernels.hpp", "rt_wide.hpp", "rt_device.hpp", "Makefile")]
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "dartray_rt.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:

@@ -91,6 +91,8 @@ typedef struct drt_counters {
     int64_t sources;       /* sources processed by the last rt_loop */
     double kernel_ms;      /* device time of the ray-tracing kernel(s) of the last rt_loop (hipEvent) */
     int64_t launches;      /* kernel launches behind kernel_ms */
+    int64_t atomic_instructions; /* f64 atomic wave-instructions issued for scaspe / u_final by the deposit loop */
+    int64_t atomic_lanes;  /* active lanes summed over those instructions (8 bytes of payload each) */
 } drt_counters;
 
 /* ---- life cycle ------------------------------------------------------------------------------- */

@@ -50,6 +50,19 @@ def cases():
         # deeper tree, strongly forward scattering, kp_sca_max=2 (192+2 scaspe slots)
         "blobC": grids.blob_case(base=(4, 2), max_lvl=4, nlambda=1, balance=False, name="blobC", tau=3.0,
                                  g=(0.7,), kp_sca_max=2),
+        # --- many wavelengths per ray: the instantiations bench.py times (rt_stage_wide<32,4>) ---
+        # TRUST-I tau_z=1 with the full 32-wavelength list on the 1 801-cell tree: slot tables [kp 1 x13, kp 0 x10,
+        # isotropic x9], 7 observer directions (55 / 19 / 8 scaspe slots)
+        "trusti32": grids.trusti_case(tau_z=1.0, max_lvl=2, wavelengths=list(range(32)), name="trusti32",
+                                      max_sca_iterations=2),
+        # 7 wavelengths (not a power of two), kp 1 / -1 / 0 interleaved so that every 4- and 8-wide wavelength block
+        # mixes slot tables; walls on, two point sources, diffuse emission
+        "blobD": grids.blob_case(base=(4, 2), max_lvl=3, nlambda=7, walls=True, name="blobD",
+                                 albedo=(0.6, 0.5, 0.4, 0.55), g=(0.55, 0.0, 0.1, 0.3, 0.05),
+                                 p_src=((0.31, -0.23, 0.13), (-2.03, 1.52, 2.46)), max_sca_iterations=3),
+        # 5 wavelengths with kp_sca_max=2: 194-slot tables (more slots than lanes) next to 50-, 14- and 3-slot ones
+        "blobE": grids.blob_case(base=(3, 3), max_lvl=2, nlambda=5, name="blobE", tau=2.0, kp_sca_max=2,
+                                 albedo=(0.6, 0.5, 0.45), g=(0.7, 0.0, 0.1, 0.3, 0.62), max_sca_iterations=3),
     }
 
 

@@ -39,7 +39,7 @@ def grids(pkg):
     return pkg.grids
 
 
-GOLDEN_CASES = ["cube65", "slab1801", "blobA", "blobB", "blobC"]
+GOLDEN_CASES = ["cube65", "slab1801", "blobA", "blobB", "blobC", "blobD", "blobE", "trusti32"]
 
 
 @pytest.fixture(scope="session")
@@ -60,13 +60,22 @@ def golden():
     return get
 
 
-def golden_scaspe_check(z, prefix, il, arr, rtol, label):
-    """Compare one scaspe array with what the fixture holds for it (full, or sums + samples)."""
+def _relelem(a, b, floor):
+    s = np.abs(b).max()
+    m = np.abs(b) > floor * s
+    return float((np.abs(a[m] - b[m]) / np.abs(b[m])).max()) if (s > 0 and m.any()) else 0.0
+
+
+def golden_scaspe_check(z, prefix, il, arr, rtol, label, rtol_elem=None, floor=1e-12):
+    """Compare one scaspe array with what the fixture holds for it (full, or sums + samples): relative to the
+    array maximum (rtol) and, when rtol_elem is given, element by element for everything above floor * maximum."""
     key = f"{prefix}{il}_full"
     if key in z:
         ref = z[key]
         scale = np.abs(ref).max()
         assert np.abs(arr - ref).max() <= rtol * scale, f"{label} {prefix}{il}"
+        if rtol_elem is not None:
+            assert _relelem(arr, ref, floor) <= rtol_elem, f"{label} {prefix}{il} element-wise"
         return
     cs, ps = z[f"{prefix}{il}_cellsum"], z[f"{prefix}{il}_pixsum"]
     assert np.abs(arr.sum(axis=1) - cs).max() <= rtol * np.abs(cs).max(), f"{label} {prefix}{il} cellsum"
@@ -74,3 +83,6 @@ def golden_scaspe_check(z, prefix, il, arr, rtol, label):
     idx, smp = z[f"{prefix}{il}_sample_idx"], z[f"{prefix}{il}_sample"]
     if idx.size:
         assert np.abs(arr[idx] - smp).max() <= rtol * np.abs(smp).max(), f"{label} {prefix}{il} samples"
+        if rtol_elem is not None:
+            assert _relelem(arr[idx], smp, floor) <= rtol_elem, f"{label} {prefix}{il} samples element-wise"
+            assert _relelem(arr.sum(axis=1), cs, floor) <= rtol_elem, f"{label} {prefix}{il} cellsum element-wise"

@@ -31,7 +31,9 @@ def stage(name, fn):
               "steps", raw[16], "busy lanes/step", round(raw[17] / max(raw[16], 1), 1),
               "deposits/group", round(raw[19] / max(raw[18], 1), 2))
     print(f"{name:14s} wall {dt*1e3:9.1f} ms kernel {ms:9.2f} ms src {c['sources']:7d} inter {c['intersections']:12d} rays {c['rays']:11d} "
-          f"sca {c['scaspe_adds']:12d} | {c['intersections']/max(ms,1e-9)*1e3:.3e} inter/s  {bytes_alg/max(ms,1e-9)*1e3/1e9:8.1f} GB/s alg", flush=True)
+          f"sca {c['scaspe_adds']:12d} | {c['intersections']/max(ms,1e-9)*1e3:.3e} inter/s  {bytes_alg/max(ms,1e-9)*1e3/1e9:8.1f} GB/s alg"
+          f" | atomics {c['atomic_instructions']:.3e} ({c['scaspe_adds']/max(c['atomic_instructions'],1):.2f} (ray,lambda)/instr, "
+          f"{c['atomic_lanes']/max(c['atomic_instructions'],1):.1f} lanes/instr, {8e-6*c['atomic_lanes']/max(ms,1e-9):.1f} GB/s payload)", flush=True)
 g.rt_prepare("start")
 print("npix", g.npix)
 stage("precalc_cell", lambda: g.rt_loop("precalc_cell")); stage("precalc_src", lambda: g.rt_loop("precalc_src")); g.rt_mpi("precalc_src")
