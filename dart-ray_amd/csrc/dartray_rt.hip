@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,7 @@ struct drt_ctx {
     bool have_par = false, have_grid = false, prepared = false, part2 = false;
     int L = 0, LP = 1;
     bool ray_major = false;
+    bool big_tables = false;  // some wavelength's slot table has more than 63 slots (set_npix_arr)
     int G_cell = 0;  // sectors per task that last fitted the queue arena for cell sources (0: not tried yet)
     std::vector<double*> d_bak_scaspe;  // snapshot of the accumulators of a stage, restored when a launch is repeated
     double *d_bak_u = nullptr, *d_bak_lost = nullptr;
@@ -108,7 +110,7 @@ struct drt_ctx {
     int spawn_cap = 0;
     size_t src_list_cap = 0;
     int* d_dbg = nullptr;
-    int dbg_cap = 0;
+    int dbg_cap = 0, dbg_flags = 0;
     double* d_ring_tab[14] = {nullptr}, *d_phi0_tab[14] = {nullptr}, *d_phi1_tab[14] = {nullptr};
     double* d_dir_out_sc = nullptr;
     int tab_max_level = 0;
@@ -344,6 +346,8 @@ static void set_npix_arr(drt_ctx* c)
         c->npix_hp[i] = 12 * (1 << (2 * k_min));
     }
     for (int i = 0; i < L; i++) c->npix[i] = c->npix_hp[i] + c->ndir;  // tot_ndir_scaspe = tot_ndir (io_routines.f90:559)
+    c->big_tables = false;
+    for (int i = 0; i < L; i++) if (c->kp[i] >= 0 && c->npix[i] > 63) c->big_tables = true;
     c->nuniq = 0; c->kp_unique.clear(); c->npix_unique.clear();
     for (int k = 0; k <= c->par.kp_sca_max; k++) {
         bool inc = false;
@@ -453,7 +457,7 @@ static int upload_problem(drt_ctx* c)
     }
     P.arena = c->d_arena;
     P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task;
-    P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap;
+    P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap; P.dbg_flags = c->dbg_flags;
     for (int k = 0; k < 14; k++) { P.ring_tab[k] = c->d_ring_tab[k]; P.phi0_tab[k] = c->d_phi0_tab[k]; P.phi1_tab[k] = c->d_phi1_tab[k]; }
     P.tab_max_level = c->tab_max_level;
     P.dir_out_sc = c->d_dir_out_sc;
@@ -471,16 +475,17 @@ template <int LP> static int stage_blocks_per_cu()
     return nb;
 }
 
-#define DRT_LB 4
-static size_t wide_lds_bytes(const drt_ctx* c) { return 4ull * (64ull * c->L + c->LP) * sizeof(double); }
-template <int LP> static int wide_blocks_per_cu(drt_ctx* c)
+static size_t wide_lds_bytes(const drt_ctx* c) { return 4ull * (64ull * c->L + c->LP + 5 * 64) * sizeof(double); }
+template <int LP, bool BIG> static int wide_blocks_per_cu_(drt_ctx* c)
 {
     int nb = 0;
     const size_t lds = wide_lds_bytes(c);
-    if (hipFuncSetAttribute((const void*)rt_stage_wide<LP, DRT_LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide<LP, DRT_LB>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipFuncSetAttribute((const void*)rt_stage_wide<LP, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide<LP, BIG>, 256, lds) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
+// the smaller of the two instantiations' answers: the arena is carved once for both
+template <int LP> static int wide_blocks_per_cu(drt_ctx* c) { return std::min(wide_blocks_per_cu_<LP, false>(c), wide_blocks_per_cu_<LP, true>(c)); }
 
 static int ensure_arena(drt_ctx* c)
 {
@@ -779,7 +784,9 @@ template <int LP> static void launch_stage(drt_ctx* c, const StageArgs& a, int b
 }
 template <int LP> static void launch_wide(drt_ctx* c, const StageArgs& a, int blocks)
 {
-    hipLaunchKernelGGL((rt_stage_wide<LP, DRT_LB>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
+    // slot tables with more slots than lanes (kp >= 2) need the instantiation with the memory-table path
+    if (c->big_tables) hipLaunchKernelGGL((rt_stage_wide<LP, true>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
+    else hipLaunchKernelGGL((rt_stage_wide<LP, false>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
 }
 template <int LP> static void launch_iobs(drt_ctx* c, int rt, int nsrc, int blocks)
 {
@@ -1201,6 +1208,15 @@ extern "C" int drt_debug_trace(drt_ctx* c, int capacity, int* out, int* count)
         HIPCHK(c, hipMalloc((void**)&c->d_dbg, (1 + 6ull * capacity) * sizeof(int)));
         HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(int)));
     }
+    if (c->prepared) return upload_problem(c);
+    return DRT_OK;
+}
+
+// Developer aid: DevProblem::dbg_flags (only builds with -DDRT_DEBUG_FLAGS look at them)
+extern "C" int drt_debug_flags(drt_ctx* c, int flags)
+{
+    if (!c) return DRT_E_ARG;
+    c->dbg_flags = flags;
     if (c->prepared) return upload_problem(c);
     return DRT_OK;
 }

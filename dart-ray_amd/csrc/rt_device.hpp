@@ -23,7 +23,7 @@ enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE =
 
 // counters[] slots
 enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7,
-       CNT_ATOM = 20, CNT_ATOM_LANES = 21, CNT_N = 24 };  // 8..19: phase timers of a -DDRT_PROFILE build
+       CNT_ATOM = 20, CNT_ATOM_LANES = 21, CNT_N = 32 };  // 8..19, 22..31: phase timers of a -DDRT_PROFILE build
 
 struct DevProblem {
     int N, max_lvl, base0, base1, L, nsrc, ndir, pabs_max;
@@ -78,6 +78,7 @@ struct DevProblem {
     // optional debug trace of ray launches: dbg[0] = count, then records of 6 ints
     int* dbg;
     int dbg_cap;
+    int dbg_flags;  // developer builds (-DDRT_DEBUG_FLAGS): bit 0 = skip the scaspe / u_final atomics of the deposit loop (timing only)
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -119,7 +119,8 @@ __device__ __forceinline__ void gatomic_add(double* p, double v)
 struct WaveCounters { unsigned long long inter, rays, deps, sca, lamdep, uadd, uread, slots;
     unsigned long long atom, atom_lanes;  // wave-uniform: atomic wave-instructions of the deposit loop and their active lanes
 #ifdef DRT_PROFILE
-    unsigned long long t_setup, t_step, t_flush, t_park, t_next, t_commit, t_extract, t_total, n_steps, n_busy_lanes, n_groups, n_deps;
+    unsigned long long t_setup, t_step, t_flush, t_park, t_next, t_commit, t_extract, t_total, n_steps, n_busy_lanes, n_groups, n_deps,
+        t_dep, t_ghead, t_memb, t_epi, n_lam, n_memb, n_cls0, n_cls1, n_cls2;  // inside the wavelength loop: deposit arithmetic, group head, member loop, epilogue + atomic
 #endif
 };
 #ifdef DRT_PROFILE

@@ -44,7 +44,15 @@ struct HotP {
     double tau_thin, cs, en_lim;
     const double *dens, *u_fest_r;
     double *u_fest, *u_final;
+#ifdef DRT_DEBUG_FLAGS
+    int skip_atomics;
+#endif
 };
+#ifdef DRT_DEBUG_FLAGS
+#define DRT_ATOMIC(H, addr, v) do { if ((H).skip_atomics) asm volatile("" ::"v"(addr), "v"(v)); else gatomic_add(addr, v); } while (0)
+#else
+#define DRT_ATOMIC(H, addr, v) gatomic_add(addr, v)
+#endif
 struct LaneTab {  // lane l: constants of wavelength l
     double g, ksca;
     int np, tid;
@@ -53,13 +61,12 @@ struct LaneTab {  // lane l: constants of wavelength l
 
 // deposit (rt_routines.f90:2362-2557) for one wavelength of this lane's ray. br: 1 = the ray is narrower
 // than the cell wants (u_fest test, :2455-2490), 2 = deposit u_final + scattered energy, 3 = precalc deposit.
+// dens = dens_arr(l, cc) and, for br == 1, u_fest = u_fest_arr(l, cc) are loaded by the caller one wavelength ahead.
 __device__ __forceinline__ void deposit_lambda(const HotP& P, double ksca_l, int rt, const SrcInfo& S, int br, int cc, int l, double length,
-                                               double beam_i, double beam_f, double csize_f, double vol_f, double& I,
-                                               double& u_add, double& en_sca, double& lost, bool& alive, WaveCounters& wc)
+                                               double dens, double u_fest, double beam_i, double beam_f, double csize_f, double vol_f,
+                                               double& I, double& u_add, double& en_sca, double& lost, bool& alive, WaveCounters& wc)
 {
     const int nc = S.nc;
-    const unsigned long long idx = (unsigned long long)cc * P.L + l;
-    const double dens = gload(P.dens + idx);
     double tau_c = dens * length;
     double ex = exp(-tau_c);
     double i_av;
@@ -79,7 +86,7 @@ __device__ __forceinline__ void deposit_lambda(const HotP& P, double ksca_l, int
     if (br == 1) {
         const double u_beam = i_av * csize_f / P.cs / vol_f * S.area_i * beam_f;
         wc.uread++;
-        if (u_beam < P.en_lim * gload(P.u_fest_r + idx)) {
+        if (u_beam < P.en_lim * u_fest) {
             I = 0;
             lost = i_av * beam_i * S.csize_i * S.csize_i;
         }
@@ -88,7 +95,7 @@ __device__ __forceinline__ void deposit_lambda(const HotP& P, double ksca_l, int
     }
     const double v = i_av * length / P.cs / vol_f * S.area_i * beam_i;
     if (br == 3) {
-        if (v != 0.0) { gatomic_add(P.u_fest + idx, v); wc.uadd++; }
+        if (v != 0.0) { gatomic_add(P.u_fest + ((unsigned long long)cc * P.L + l), v); wc.uadd++; }
     } else {
         u_add = v;
         if (v != 0.0) wc.uadd++;
@@ -106,123 +113,133 @@ __device__ __forceinline__ void deposit_lambda(const HotP& P, double ksca_l, int
     else if (!(tau_c < P.tau_thin)) I = I / (tau_c) * (1 - ex);
 }
 
-// process_scatt_rad (rt_routines.f90:2638-2726) + the u_final update (:2497-2505) for LB wavelengths
-// l0 .. l0+LB-1 of all rays of this step: rays in the same cell are summed on chip. Lanes 0..np-1 are the
-// scaspe slots, lane 63 carries u_final in the same atomic instruction.
+// x**(-1.5) with fused multiply-adds (weights only: nothing decides on them). Same accuracy as pow_m1p5 (1.3e-14).
+__device__ __forceinline__ double pow_m1p5_f(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-(hx * y), y, 1.5);
+    return (y * y) * y;
+}
+
+// process_scatt_rad (rt_routines.f90:2638-2726) + the u_final update (:2497-2505) for ONE wavelength l of all rays
+// of this step. M = lanes (rays) with something to deposit; rays in the same cell are summed on chip. Lanes
+// 0..np-1 are the scaspe slots of the cell, lane 63 carries u_final in the same atomic instruction.
 //
 // Slot tables: set_npix_arr (rt_routines.f90:5235-5315) gives a wavelength 12*4^kp HEALPix slots + tot_ndir
 // observer slots. Only kp = 0 and kp = 1 can fit the 63 slot lanes, so the unit vectors of (at most) those two
 // tables live in registers (SlotTabs, slot = lane) and every wavelength using one of them - and the isotropic
 // ones - takes the merged path: ONE f64 atomic instruction per (cell group, wavelength). Tables with more
 // slots than lanes (kp >= 2) go through memory 64 slots at a time, merged over the rays of the group as well.
-template <int LB>
-__device__ __forceinline__ void flush_block(const DevProblem& P, int cc, double rnx, double rny, double rnz, const double (&C)[LB],
-                                            const double (&U)[LB], int l0, const SlotTabs& T, const HotP& H, const LaneTab& LT,
-                                            WaveCounters& wc)
+//
+// The code exists once (the wavelength loop of the caller is not unrolled): the stage kernel's hot loop stays small
+// enough for the instruction cache two CUs share, and one C / U / accumulator pair is live instead of four.
+// Cross-lane broadcasts go through LDS: the depositing lanes stage (C, U) of the wavelength and every ray its
+// direction (stg: [5][64] doubles per wave: C, U, nx, ny, nz); the member loop then reads a ray's values with
+// uniform-address ds_reads (one LDS instruction per double, no VALU slot) instead of two v_readlane per double -
+// the loop is VALU-issue-bound and ten of its ~22 vector instructions per ray were readlanes.
+template <bool BIG>
+__device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long long M, unsigned long long MC, int cc, const ldouble* stg,
+                                             int l, const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc)
 {
     const int lane = lane_id();
-    bool mine = false;
-#pragma unroll
-    for (int k = 0; k < LB; k++) mine = mine || (C[k] != 0.0 || U[k] != 0.0);
-    unsigned long long pend = __ballot(mine);
-    if (!pend) return;
-    // wave-uniform constants of the LB wavelengths. regk: 0 / 1 = register table, -1 = isotropic, 2 = memory table
-    int npk[LB], regk[LB];
-    double gak[LB], gbk[LB];
-    double* srk[LB];
-    bool need0 = false, need1 = false, big = false;
-#pragma unroll
-    for (int k = 0; k < LB; k++) {
-        const int l = min(l0 + k, H.L - 1);
-        const double g = readlane_d(LT.g, l);
-        npk[k] = (l0 + k < H.L) ? __builtin_amdgcn_readlane(LT.np, l) : 0;
-        const int tid = __builtin_amdgcn_readlane(LT.tid, l);
-        regk[k] = (tid < 0) ? -1 : (tid <= 1 && npk[k] <= 63) ? tid : 2;
-        need0 = need0 || (regk[k] == 0 && npk[k] > 0);
-        need1 = need1 || (regk[k] == 1 && npk[k] > 0);
-        big = big || (regk[k] == 2 && npk[k] > 0);
-        gak[k] = 1.0 + g * g; gbk[k] = 2.0 * g;
-        srk[k] = (double*)readlane_u64(LT.srow, l);
-    }
-    while (pend) {
-        const int src = __ffsll((long long)pend) - 1;
+    const bool mine = (M >> lane) & 1ull;
+    // wave-uniform constants of the wavelength (scalar registers)
+    const double g = readlane_d(LT.g, l);
+    const int np = __builtin_amdgcn_readlane(LT.np, l);
+    const int tid = __builtin_amdgcn_readlane(LT.tid, l);
+    const int reg = (tid < 0) ? -1 : (tid <= 1 && np <= 63) ? tid : 2;  // 0 / 1: register table, -1: isotropic, 2: memory table
+    const unsigned long long srow0 = readlane_u64(LT.srow, l);
+    const double ga = 1.0 + g * g, gb = 2.0 * g;
+    const double tx = (reg == 1) ? T.x1 : T.x0, ty = (reg == 1) ? T.y1 : T.y0, tz = (reg == 1) ? T.z1 : T.z0;
+    while (M) {
+        TSTAMP(tg0);
+        const int src = __ffsll((long long)M) - 1;
         const int cc_b = __builtin_amdgcn_readlane(cc, src);
         const unsigned long long grp = __ballot(mine && cc == cc_b);
-        pend &= ~grp;
-        double acc[LB], su[LB];
-#pragma unroll
-        for (int k = 0; k < LB; k++) { acc[k] = 0.0; su[k] = 0.0; }
-        unsigned long long gm = grp;
-        while (gm) {
-            const int m = __ffsll((long long)gm) - 1;
-            gm &= gm - 1;
-            const double nx = readlane_d(rnx, m), ny = readlane_d(rny, m), nz = readlane_d(rnz, m);
-            double cs0 = 0.0, cs1 = 0.0;
-            if (need0) cs0 = T.x0 * nx + T.y0 * ny + T.z0 * nz;
-            if (need1) cs1 = T.x1 * nx + T.y1 * ny + T.z1 * nz;
-#pragma unroll
-            for (int k = 0; k < LB; k++) {
-                const double Cm = readlane_d(C[k], m);
-                su[k] += readlane_d(U[k], m);
-                if (Cm != 0.0 && regk[k] < 2) {  // skipping the zeros beats a branch-free loop (1666 vs 1789 ms): 45 % of the entries are zero
-                    if (regk[k] < 0) acc[k] += Cm;  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
-                    else acc[k] += Cm * pow_m1p5(gak[k] - gbk[k] * (regk[k] == 1 ? cs1 : cs0));
+        M &= ~grp;
+#ifdef DRT_PROFILE
+        wc.n_groups++; wc.n_memb += __popcll(grp);
+        if (reg < 0) wc.n_cls2 += __popcll(grp); else if (reg == 0) wc.n_cls0 += __popcll(grp); else wc.n_cls1 += __popcll(grp);
+#endif
+        const unsigned long long row = srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)np);
+        const unsigned long long urow = (unsigned long long)H.u_final + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)H.L + (unsigned)l);
+        double su = 0.0;
+        unsigned long long gc = grp & MC;   // members with scattered energy
+        unsigned long long gu = grp & ~MC;  // members that only add to u_final
+        while (gu) {
+            const int m = __ffsll((long long)gu) - 1;
+            gu &= gu - 1;
+            su += stg[64 + m];
+        }
+        TSTAMP(tg1);
+        TACC(t_ghead, tg0, tg1);
+        if (!BIG || reg < 2) {
+            double acc = 0.0;
+            if (reg < 0) {  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
+                while (gc) {
+                    const int m = __ffsll((long long)gc) - 1;
+                    gc &= gc - 1;
+                    acc += stg[m];
+                    su += stg[64 + m];
+                }
+            } else {
+                while (gc) {
+                    const int m = __ffsll((long long)gc) - 1;
+                    gc &= gc - 1;
+                    const double Cm = stg[m];
+                    su += stg[64 + m];
+                    const double nx = stg[128 + m], ny = stg[192 + m], nz = stg[256 + m];
+                    const double cs = __builtin_fma(tz, nz, __builtin_fma(ty, ny, tx * nx));
+                    acc = __builtin_fma(Cm, pow_m1p5_f(__builtin_fma(-gb, cs, ga)), acc);
                 }
             }
-        }
-#pragma unroll
-        for (int k = 0; k < LB; k++) {
-            const int np = npk[k];
-            if (np > 0) {
-                double* uaddr = H.u_final + (unsigned long long)cc_b * H.L + (l0 + k);
-                double* addr = (lane == 63) ? uaddr : (srk[k] + (unsigned long long)cc_b * np + lane);
-                const double v = (lane == 63) ? su[k] : acc[k];
-                const bool go = ((regk[k] < 2 && lane < np) || lane == 63) && v != 0.0;
+            TSTAMP(tg2);
+            TACC(t_memb, tg1, tg2);
+            double* const addr = (double*)((lane == 63) ? urow : row + 8ull * (unsigned)lane);
+            const double v = (lane == 63) ? su : acc;
+            const bool go = (lane < np || lane == 63) && v != 0.0;
+            const unsigned long long gb_ = __ballot(go);
+            if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
+            if (go) DRT_ATOMIC(H, addr, v);
+            TSTAMP(tg3);
+            TACC(t_epi, tg2, tg3);
+        } else {
+            // slot table with more slots than lanes: 64 slots at a time from memory, the rays of the group summed per slot
+            const double* tab = P.tab[l];
+            for (int p0 = 0; p0 < np; p0 += 64) {
+                const int p = p0 + lane;
+                double px = 0, py = 0, pz = 0;
+                if (p < np) { px = gload(tab + p); py = gload(tab + np + p); pz = gload(tab + 2 * np + p); }
+                double a2 = 0.0;
+                unsigned long long g2 = gc;
+                while (g2) {
+                    const int m = __ffsll((long long)g2) - 1;
+                    g2 &= g2 - 1;
+                    const double Cm = stg[m];
+                    if (p0 == 0) su += stg[64 + m];
+                    const double nx = stg[128 + m], ny = stg[192 + m], nz = stg[256 + m];
+                    const double cs = __builtin_fma(pz, nz, __builtin_fma(py, ny, px * nx));
+                    a2 = __builtin_fma(Cm, pow_m1p5_f(__builtin_fma(-gb, cs, ga)), a2);
+                }
+                const bool go = (p < np) && a2 != 0.0;
                 const unsigned long long gb_ = __ballot(go);
                 if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
-                if (go) gatomic_add(addr, v);
+                if (go) DRT_ATOMIC(H, (double*)(row + 8ull * (unsigned)p), a2);
             }
-        }
-        if (big) {
-            // slot tables with more slots than lanes: 64 slots at a time from memory, the rays of the group summed per slot
-#pragma unroll
-            for (int k = 0; k < LB; k++) {
-                if (regk[k] == 2 && npk[k] > 0) {
-                    const int np = npk[k];
-                    const double* tab = P.tab[l0 + k];
-                    double* srow = srk[k] + (unsigned long long)cc_b * np;
-                    for (int p0 = 0; p0 < np; p0 += 64) {
-                        const int p = p0 + lane;
-                        double px = 0, py = 0, pz = 0;
-                        if (p < np) { px = gload(tab + p); py = gload(tab + np + p); pz = gload(tab + 2 * np + p); }
-                        double a2 = 0.0;
-                        unsigned long long g2 = grp;
-                        while (g2) {
-                            const int m = __ffsll((long long)g2) - 1;
-                            g2 &= g2 - 1;
-                            const double Cm = readlane_d(C[k], m);
-                            if (Cm != 0.0) {
-                                const double nx = readlane_d(rnx, m), ny = readlane_d(rny, m), nz = readlane_d(rnz, m);
-                                a2 += Cm * pow_m1p5(gak[k] - gbk[k] * (px * nx + py * ny + pz * nz));
-                            }
-                        }
-                        const bool go = (p < np) && a2 != 0.0;
-                        const unsigned long long gb_ = __ballot(go);
-                        if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
-                        if (go) gatomic_add(&srow[p], a2);
-                    }
-                }
-            }
+            const bool gu1 = (lane == 63) && su != 0.0;
+            if (__ballot(gu1)) { wc.atom++; wc.atom_lanes++; }
+            if (gu1) DRT_ATOMIC(H, (double*)urow, su);
         }
     }
 }
 
 // trace_items of rt_kernels.hpp with lane = ray. Ilds: [L][64] LDS intensities of the wave, thg: [L][64]
 // arena, ll: [L] LDS lum_lost of the running task.
-template <int LP, int LB>
+template <int LP, bool BIG>
 __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
                               const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
-                              int* __restrict__ ostat, int level, ldouble* Ilds, double* __restrict__ thg, ldouble* ll,
+                              int* __restrict__ ostat, int level, ldouble* Ilds, double* __restrict__ thg, ldouble* ll, ldouble* bst,
                               const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc, int& err)
 {
     const int lane = lane_id();
@@ -313,6 +330,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                 nx = p1.st * p1.cp; ny = p1.st * p1.sp; nz = p1.ct;
                             }
                             r.nx = nx; r.ny = ny; r.nz = nz;
+                            bst[128 + lane] = nx; bst[192 + lane] = ny; bst[256 + lane] = nz;  // read by every lane in flush_lambda
                             busy = true;
                             fresh = true;
                             my_item = item - chunk_base;
@@ -406,7 +424,20 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
             int isel = 0;
             int br = 0;
             double beam_i = 0, beam_f = 0, csize_f = 0, vol_f = 0;
-            if (busy) {
+            // Phase alignment: rays of one source that cross the same cell enter it at nearly the same distance from
+            // the source, but after different numbers of steps (different start cells, cell sizes, obliquity). Only
+            // the lanes within DRT_PHASE_K cell sizes of the wave's smallest entry distance take this step; the
+            // others wait in place, so that the rays of a cell deposit in the same step and leave the wave in one
+            // atomic. Pure scheduling: what a ray does does not depend on when it does it.
+            bool go = busy;
+#if defined(DRT_PHASE_K)
+            if (a.scatter) {
+                double pm = busy ? r.prev : 1.0e300;
+                for (int off = 1; off < 64; off <<= 1) pm = fmin(pm, __shfl_xor(pm, off, 64));
+                go = busy && (r.prev <= pm + (DRT_PHASE_K) * P.csize_arr[r.clvl]);
+            }
+#endif
+            if (go) {
                 wc.inter++;
                 calc_psel(P, S, r, psel, isel);
                 length = psel - r.prev;
@@ -438,31 +469,60 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
             }
             TSTAMP(ts2);
             TACC(t_step, ts1, ts2);
-            // ---- the wavelengths of the step, LB at a time ---------------------------------------------------
+            // ---- the wavelengths of the step: one at a time, operands fetched one wavelength ahead ---------------
             bool alive = false;
             if (__ballot(br != 0)) {
-                for (int l0 = 0; l0 < L; l0 += LB) {
-                    const unsigned long long bits = (amask >> l0) & ((1ull << LB) - 1ull);
-                    if (!__ballot(br != 0 && bits != 0ull)) continue;
-                    double C[LB], U[LB];
-#pragma unroll
-                    for (int k = 0; k < LB; k++) {
-                        C[k] = 0.0; U[k] = 0.0;
-                        const int l = l0 + k;
-                        if (br != 0 && ((bits >> k) & 1ull)) {
+                const int cc_s = r.cc;
+                // operands of wavelength l for this lane: dens_arr(l, cc) and, in ONE more load whose meaning follows the
+                // branch, u_fest_arr(l, cc) (br 1) or the ray's HG normalisation (br 2)
+                const double* const p_dens = H.dens + (unsigned long long)cc_s * L;
+                const double* const p_aux = (br == 1) ? H.u_fest_r + (unsigned long long)cc_s * L : (br == 2) ? thg + lane : p_dens;
+                const int aux_stride = (br == 2) ? 64 : 1;
+                double dn = 0.0, ax = 1.0;
+                if (br != 0 && (amask & 1ull)) { dn = gload(p_dens); ax = gload(p_aux); }
+#pragma nounroll
+                for (int l = 0; l < L; l++) {
+                    double dn1 = 0.0, ax1 = 1.0;
+                    if (l + 1 < L && br != 0 && ((amask >> (l + 1)) & 1ull)) { dn1 = gload(p_dens + (l + 1)); ax1 = gload(p_aux + (l + 1) * aux_stride); }
+                    const bool act = br != 0 && ((amask >> l) & 1ull);
+                    if (__ballot(act)) {
+                        TSTAMP(td0);
+#ifdef DRT_PROFILE
+                        wc.n_lam++;
+#endif
+                        double C = 0.0, U = 0.0;
+                        if (act) {
                             double I = Ilds[l * 64 + lane];
                             double e = 0.0, lost = 0.0;
-                            deposit_lambda(H, readlane_d(LT.ksca, l), rt, S, br, r.cc, l, length, beam_i, beam_f, csize_f, vol_f, I, U[k], e, lost, alive, wc);
+                            deposit_lambda(H, readlane_d(LT.ksca, l), rt, S, br, cc_s, l, length, dn, ax, beam_i, beam_f, csize_f, vol_f, I, U, e, lost, alive, wc);
                             Ilds[l * 64 + lane] = I;
                             if (lost != 0.0) (void)__hip_atomic_fetch_add(ll + l, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (e != 0.0) {
-                                C[k] = e / gload(thg + l * 64 + lane);
+                                C = e / ax;
                                 wc.sca++;
                                 wc.slots += (unsigned long long)__builtin_amdgcn_readlane(LT.np, l);
                             }
                         }
+                        TSTAMP(td1);
+                        TACC(t_dep, td0, td1);
+                        if (a.scatter) {
+                            const unsigned long long MC = __ballot(C != 0.0);
+                            const unsigned long long M = MC | __ballot(U != 0.0);
+                            if (M) {
+                                // stage (C, U) of this wavelength for the uniform-address reads of flush_lambda; LDS
+                                // operations of one wave execute in issue order, the fences keep the compiler from
+                                // moving the reads of other lanes' values above these writes
+                                bst[lane] = C; bst[64 + lane] = U;
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                flush_lambda<BIG>(P, M, MC, cc_s, bst, l, T, H, LT, wc);
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
                     }
-                    if (a.scatter) flush_block<LB>(P, r.cc, r.nx, r.ny, r.nz, C, U, l0, T, H, LT, wc);
+                    dn = dn1; ax = ax1;
                 }
             }
             if (br == 1) {
@@ -473,7 +533,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
             TACC(t_flush, ts2, ts3);
 
             // ---- blocked rays are parked at their item's index (add_to_high/low_ray_list, ray_list.f90:463-579)
-            if (busy && (status == ST_GO_HIGH || status == ST_GO_LOW)) {
+            if (go && (status == ST_GO_HIGH || status == ST_GO_LOW)) {
                 const bool hi = (status == ST_GO_HIGH);
                 const double dpl = r.prev / ((r.isel_old == 1) ? r.cpi0 : (r.isel_old == 2) ? r.cpi1 : r.cpi2);
                 stg.ipix[my_item] = (uint32_t)r.ipix_dir;
@@ -485,12 +545,12 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 ostat[my_item] = hi ? 1 : 2;
                 for (int l = 0; l < L; l++) stg.lum[(unsigned long long)my_item * LP + l] = Ilds[l * 64 + lane] * S.norm;
             }
-            if (busy && status != ST_CONT) busy = false;
+            if (go && status != ST_CONT) { busy = false; go = false; }
             TSTAMP(ts4);
             TACC(t_park, ts3, ts4);
 
             // ---- next cell --------------------------------------------------------------------------------
-            if (busy) {
+            if (go) {
                 r.prev = psel;
                 r.isel_old = isel;
                 r.clvl_old = r.clvl;
@@ -534,9 +594,10 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 }
 
 // rt_loop + main_dir_loop (rt_routines.f90:985-1058, 1343-1467), ray-major. LP is the row stride of the
-// luminosity arrays in the queues (next power of two >= lnum), LB the wavelengths handled per register tile.
-// Dynamic LDS: per wave (64 * L + LP) doubles.
-template <int LP, int LB>
+// luminosity arrays in the queues (next power of two >= lnum); BIG: some slot table has more slots than lanes (kp >= 2),
+// the instantiation without it has no memory-table path in its deposit loop.
+// Dynamic LDS: per wave (64 * L + LP + 5 * 64) doubles.
+template <int LP, bool BIG>
 __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
 {
     extern __shared__ double lds_w[];
@@ -548,8 +609,9 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     // then lives in scalar registers instead of 50+ vector registers that are spilled inside divergent code
     const int wib = first_lane_i((int)(threadIdx.x >> 6));
     const int gwave = blockIdx.x * waves_per_block + wib;
-    ldouble* Ilds = (ldouble*)lds_w + wib * (64 * L + LP);
+    ldouble* Ilds = (ldouble*)lds_w + wib * (64 * L + LP + 5 * 64);
     ldouble* ll = Ilds + 64 * L;
+    ldouble* bst = ll + LP;  // [5][64]: C, U of the wavelength being flushed; nx, ny, nz of every ray
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
     int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]
@@ -569,6 +631,9 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     HotP H;
     H.L = P.L; H.tau_thin = P.tau_thin; H.cs = P.cs; H.en_lim = P.en_lim;
     H.dens = P.dens; H.u_fest_r = P.u_fest; H.u_fest = P.u_fest; H.u_final = P.u_final;
+#ifdef DRT_DEBUG_FLAGS
+    H.skip_atomics = P.dbg_flags & 1;
+#endif
     LaneTab LT = {0.0, 0.0, 0, -1, 0ull};
     if (lane < P.L) { LT.g = P.g[lane]; LT.ksca = P.ksca[lane]; LT.np = P.npix[lane]; LT.tid = P.tabid[lane]; LT.srow = (unsigned long long)P.scaspe[lane]; }
     SlotTabs T = {0, 0, 0, 0, 0, 0};
@@ -648,7 +713,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
             }
             const ListView in = (mode == 0) ? Hc : Hn;
             const ListView oh = (mode == 0) ? Hn : Hc;
-            if (n_in > 0) trace_items_w<LP, LB>(P, a, S, mode, in, n_in, oh, n_oh, LW, nL, ST, ostat, level, Ilds, thg, ll, T, H, LT, wc, err);
+            if (n_in > 0) trace_items_w<LP, BIG>(P, a, S, mode, in, n_in, oh, n_oh, LW, nL, ST, ostat, level, Ilds, thg, ll, bst, T, H, LT, wc, err);
             wave_fence();
             if (mode == 0) {
                 ListView t = Hc; Hc = Hn; Hn = t;
@@ -713,6 +778,10 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         atomicAdd(&P.counters[11], wc.t_park); atomicAdd(&P.counters[12], wc.t_next); atomicAdd(&P.counters[13], wc.t_commit);
         atomicAdd(&P.counters[14], wc.t_extract); atomicAdd(&P.counters[15], tk1 - tk0);
         atomicAdd(&P.counters[16], wc.n_steps); atomicAdd(&P.counters[17], wc.n_busy_lanes);
+        atomicAdd(&P.counters[18], wc.n_groups); atomicAdd(&P.counters[19], wc.n_memb);
+        atomicAdd(&P.counters[22], wc.t_dep); atomicAdd(&P.counters[23], wc.t_ghead); atomicAdd(&P.counters[24], wc.t_memb);
+        atomicAdd(&P.counters[25], wc.t_epi); atomicAdd(&P.counters[26], wc.n_lam);
+        atomicAdd(&P.counters[27], wc.n_cls0); atomicAdd(&P.counters[28], wc.n_cls1); atomicAdd(&P.counters[29], wc.n_cls2);
 #endif
         if (err) atomicOr(P.error, err);
     }

@@ -2,6 +2,7 @@
 """Developer tool: time every stage of a TRUST-I run on the GPU.
 usage: python tools/probe.py <max_lvl> <nlambda> [tau_z] [max_iter]"""
 import os, sys, time
+import ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,14 +23,17 @@ def stage(name, fn):
     ms = c["kernel_ms"]
     import ctypes as C
     if os.environ.get("DRT_PROFILE"):
-        raw = (C.c_ulonglong * 24)()
+        raw = (C.c_ulonglong * 32)()
         g.L_.drt_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-        g.L_.drt_debug_counters(g.h, raw, 24)
+        g.L_.drt_debug_counters(g.h, raw, 32)
         tot = max(raw[15], 1)
         names = ["setup", "step", "flush", "park", "next", "commit", "extract"]
         print("    phases % of wave time:", {n: round(100 * raw[8 + i] / tot, 1) for i, n in enumerate(names)},
               "steps", raw[16], "busy lanes/step", round(raw[17] / max(raw[16], 1), 1),
-              "deposits/group", round(raw[19] / max(raw[18], 1), 2))
+              "rays/group", round(raw[19] / max(raw[18], 1), 2))
+        print("    wavelength loop % of wave time:", {n: round(100 * raw[22 + i] / tot, 1) for i, n in enumerate(["deposit", "group head", "members", "epilogue"])},
+              "lambda iterations/step", round(raw[26] / max(raw[16], 1), 1), "groups/step", round(raw[18] / max(raw[16], 1), 1),
+              "member iterations/step by table (kp0, kp1 or memory, isotropic)", [round(raw[27 + i] / max(raw[16], 1), 1) for i in range(3)])
     print(f"{name:14s} wall {dt*1e3:9.1f} ms kernel {ms:9.2f} ms src {c['sources']:7d} inter {c['intersections']:12d} rays {c['rays']:11d} "
           f"sca {c['scaspe_adds']:12d} | {c['intersections']/max(ms,1e-9)*1e3:.3e} inter/s  {bytes_alg/max(ms,1e-9)*1e3/1e9:8.1f} GB/s alg"
           f" | atomics {c['atomic_instructions']:.3e} ({c['scaspe_adds']/max(c['atomic_instructions'],1):.2f} (ray,lambda)/instr, "
@@ -41,6 +45,9 @@ g.rt_prepare("prep_part2")
 stage("dir_cell", lambda: g.rt_loop("dir_cell")); stage("dir_src", lambda: g.rt_loop("dir_src")); g.rt_mpi("dir_src")
 stage("iobs_dir", lambda: (g.rt_loop_iobs("i_obs_dir_cell"), g.rt_loop_iobs("i_obs_dir_src")))
 it = 0
+if os.environ.get("DRT_SKIP_SCATT_ATOMICS"):
+    g.L_.drt_debug_flags.argtypes = [C.c_void_p, C.c_int]
+    g.L_.drt_debug_flags(g.h, 1)
 while not g.scatt_prepare():
     it += 1
     stage(f"scatt{it}", lambda: g.rt_loop("scatt")); g.rt_mpi("scatt")
