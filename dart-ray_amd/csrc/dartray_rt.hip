@@ -475,7 +475,7 @@ template <int LP> static int stage_blocks_per_cu()
     return nb;
 }
 
-static size_t wide_lds_bytes(const drt_ctx* c) { return 4ull * (64ull * c->L + c->LP + 5 * 64) * sizeof(double); }
+static size_t wide_lds_bytes(const drt_ctx* c) { return 4ull * (DRT_I_WORDS(c->L) + c->LP + 5 * DRT_BST + 3) * sizeof(double); }
 template <int LP, bool BIG> static int wide_blocks_per_cu_(drt_ctx* c)
 {
     int nb = 0;
@@ -530,14 +530,14 @@ static int ensure_arena(drt_ctx* c)
 static int carve_arena(drt_ctx* c, int waves, StageArgs& a)
 {
     const unsigned long long per_ray = 4ull * (28 + 8ull * c->LP) + 4ull * 20 + 8 + 16;
-    unsigned long long cap = (c->arena_bytes / (unsigned long long)waves - 512ull * c->LP - 272) / per_ray;
+    unsigned long long cap = (c->arena_bytes / (unsigned long long)waves - 1024ull * c->LP - 272) / per_ray;
     if (cap > (1ull << 22)) cap = 1ull << 22;
     cap = cap / 64 * 64;
     if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, waves);
     int hcap = 64;
     while (hcap < 2 * (int)cap) hcap <<= 1;
     for (;;) {
-        unsigned long long stride = 4ull * list_bytes((int)cap, c->LP) + 20ull * hcap + 8ull * cap + 512ull * c->LP + 16;
+        unsigned long long stride = 4ull * list_bytes((int)cap, c->LP) + 20ull * hcap + 8ull * cap + 1024ull * c->LP + 16;  // ... + thg [L][64] + (DRT_I_GLOBAL) intensities [L][64]
         stride = (stride + 255) / 256 * 256;
         if (stride * (unsigned long long)waves <= c->arena_bytes) { a.cap = (int)cap; a.hcap = hcap; a.wave_stride = stride; break; }
         cap -= 64;

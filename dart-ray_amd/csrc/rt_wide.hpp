@@ -39,6 +39,15 @@ struct SlotTabs { double x0, y0, z0, x1, y1, z1; };  // unit vectors of scaspe s
 // compiler cannot infer the space (e.g. at -O1), and a FLAT f64 atomic on an LDS address raises
 // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
 typedef __attribute__((address_space(3))) double ldouble;
+// Ray intensities [L][64] of the wave: LDS by default; -DDRT_I_GLOBAL keeps them in the wave's arena slice instead (after the
+// HG normalisations), which frees 16 KB of LDS per wave at 32 wavelengths, i.e. lifts the LDS limit on resident waves.
+#ifdef DRT_I_GLOBAL
+typedef double* iptr_t;
+#define DRT_I_WORDS(L) 0
+#else
+typedef ldouble* iptr_t;
+#define DRT_I_WORDS(L) (64 * (L))
+#endif
 struct HotP {
     int L;
     double tau_thin, cs, en_lim;
@@ -135,15 +144,16 @@ __device__ __forceinline__ double pow_m1p5_f(double x)
 // The code exists once (the wavelength loop of the caller is not unrolled): the stage kernel's hot loop stays small
 // enough for the instruction cache two CUs share, and one C / U / accumulator pair is live instead of four.
 // Cross-lane broadcasts go through LDS: the depositing lanes stage (C, U) of the wavelength and every ray its
-// direction (stg: [5][64] doubles per wave: C, U, nx, ny, nz); the member loop then reads a ray's values with
+// direction (bst: [5][DRT_BST] doubles per wave: C, U, nx, ny, nz); the member loop then reads a ray's values with
 // uniform-address ds_reads (one LDS instruction per double, no VALU slot) instead of two v_readlane per double -
 // the loop is VALU-issue-bound and ten of its ~22 vector instructions per ray were readlanes.
+#define DRT_BST 64  // row length of the broadcast staging area
 template <bool BIG>
-__device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long long M, unsigned long long MC, int cc, const ldouble* stg,
+__device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long long M, unsigned long long MC, int cc, double U, const ldouble* bst,
                                              int l, const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc)
 {
     const int lane = lane_id();
-    const bool mine = (M >> lane) & 1ull;
+    const unsigned long long Mall = M;
     // wave-uniform constants of the wavelength (scalar registers)
     const double g = readlane_d(LT.g, l);
     const int np = __builtin_amdgcn_readlane(LT.np, l);
@@ -152,11 +162,12 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
     const unsigned long long srow0 = readlane_u64(LT.srow, l);
     const double ga = 1.0 + g * g, gb = 2.0 * g;
     const double tx = (reg == 1) ? T.x1 : T.x0, ty = (reg == 1) ? T.y1 : T.y0, tz = (reg == 1) ? T.z1 : T.z0;
+    unsigned na = 0, nl = 0;  // atomic instructions and their active lanes (wave-uniform, scalar registers)
     while (M) {
         TSTAMP(tg0);
         const int src = __ffsll((long long)M) - 1;
         const int cc_b = __builtin_amdgcn_readlane(cc, src);
-        const unsigned long long grp = __ballot(mine && cc == cc_b);
+        const unsigned long long grp = __ballot(cc == cc_b) & Mall;
         M &= ~grp;
 #ifdef DRT_PROFILE
         wc.n_groups++; wc.n_memb += __popcll(grp);
@@ -167,10 +178,10 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
         double su = 0.0;
         unsigned long long gc = grp & MC;   // members with scattered energy
         unsigned long long gu = grp & ~MC;  // members that only add to u_final
-        while (gu) {
+        while (gu) {  // rays in cells without dust: no LDS round trip, their U is still in a register
             const int m = __ffsll((long long)gu) - 1;
             gu &= gu - 1;
-            su += stg[64 + m];
+            su += readlane_d(U, m);
         }
         TSTAMP(tg1);
         TACC(t_ghead, tg0, tg1);
@@ -180,16 +191,16 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
                 while (gc) {
                     const int m = __ffsll((long long)gc) - 1;
                     gc &= gc - 1;
-                    acc += stg[m];
-                    su += stg[64 + m];
+                    acc += bst[m];
+                    su += bst[DRT_BST + m];
                 }
             } else {
                 while (gc) {
                     const int m = __ffsll((long long)gc) - 1;
                     gc &= gc - 1;
-                    const double Cm = stg[m];
-                    su += stg[64 + m];
-                    const double nx = stg[128 + m], ny = stg[192 + m], nz = stg[256 + m];
+                    const double Cm = bst[m];
+                    su += bst[DRT_BST + m];
+                    const double nx = bst[2 * DRT_BST + m], ny = bst[3 * DRT_BST + m], nz = bst[4 * DRT_BST + m];
                     const double cs = __builtin_fma(tz, nz, __builtin_fma(ty, ny, tx * nx));
                     acc = __builtin_fma(Cm, pow_m1p5_f(__builtin_fma(-gb, cs, ga)), acc);
                 }
@@ -200,7 +211,7 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
             const double v = (lane == 63) ? su : acc;
             const bool go = (lane < np || lane == 63) && v != 0.0;
             const unsigned long long gb_ = __ballot(go);
-            if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
+            na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
             if (go) DRT_ATOMIC(H, addr, v);
             TSTAMP(tg3);
             TACC(t_epi, tg2, tg3);
@@ -216,22 +227,23 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
                 while (g2) {
                     const int m = __ffsll((long long)g2) - 1;
                     g2 &= g2 - 1;
-                    const double Cm = stg[m];
-                    if (p0 == 0) su += stg[64 + m];
-                    const double nx = stg[128 + m], ny = stg[192 + m], nz = stg[256 + m];
+                    const double Cm = bst[m];
+                    if (p0 == 0) su += bst[DRT_BST + m];
+                    const double nx = bst[2 * DRT_BST + m], ny = bst[3 * DRT_BST + m], nz = bst[4 * DRT_BST + m];
                     const double cs = __builtin_fma(pz, nz, __builtin_fma(py, ny, px * nx));
                     a2 = __builtin_fma(Cm, pow_m1p5_f(__builtin_fma(-gb, cs, ga)), a2);
                 }
                 const bool go = (p < np) && a2 != 0.0;
                 const unsigned long long gb_ = __ballot(go);
-                if (gb_) { wc.atom++; wc.atom_lanes += (unsigned long long)__popcll(gb_); }
+                na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
                 if (go) DRT_ATOMIC(H, (double*)(row + 8ull * (unsigned)p), a2);
             }
             const bool gu1 = (lane == 63) && su != 0.0;
-            if (__ballot(gu1)) { wc.atom++; wc.atom_lanes++; }
+            if (__ballot(gu1)) { na++; nl++; }
             if (gu1) DRT_ATOMIC(H, (double*)urow, su);
         }
     }
+    wc.atom += na; wc.atom_lanes += nl;
 }
 
 // trace_items of rt_kernels.hpp with lane = ray. Ilds: [L][64] LDS intensities of the wave, thg: [L][64]
@@ -239,7 +251,7 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
 template <int LP, bool BIG>
 __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
                               const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
-                              int* __restrict__ ostat, int level, ldouble* Ilds, double* __restrict__ thg, ldouble* ll, ldouble* bst,
+                              int* __restrict__ ostat, int level, iptr_t Ilds, double* __restrict__ thg, ldouble* ll, ldouble* bst,
                               const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc, int& err)
 {
     const int lane = lane_id();
@@ -330,7 +342,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                 nx = p1.st * p1.cp; ny = p1.st * p1.sp; nz = p1.ct;
                             }
                             r.nx = nx; r.ny = ny; r.nz = nz;
-                            bst[128 + lane] = nx; bst[192 + lane] = ny; bst[256 + lane] = nz;  // read by every lane in flush_lambda
+                            bst[2 * DRT_BST + lane] = nx; bst[3 * DRT_BST + lane] = ny; bst[4 * DRT_BST + lane] = nz;  // read by every lane in flush_lambda
                             busy = true;
                             fresh = true;
                             my_item = item - chunk_base;
@@ -512,11 +524,11 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                 // stage (C, U) of this wavelength for the uniform-address reads of flush_lambda; LDS
                                 // operations of one wave execute in issue order, the fences keep the compiler from
                                 // moving the reads of other lanes' values above these writes
-                                bst[lane] = C; bst[64 + lane] = U;
+                                bst[lane] = C; bst[DRT_BST + lane] = U;
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                 __builtin_amdgcn_wave_barrier();
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                                flush_lambda<BIG>(P, M, MC, cc_s, bst, l, T, H, LT, wc);
+                                flush_lambda<BIG>(P, M, MC, cc_s, U, bst, l, T, H, LT, wc);
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                 __builtin_amdgcn_wave_barrier();
                             }
@@ -596,7 +608,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 // rt_loop + main_dir_loop (rt_routines.f90:985-1058, 1343-1467), ray-major. LP is the row stride of the
 // luminosity arrays in the queues (next power of two >= lnum); BIG: some slot table has more slots than lanes (kp >= 2),
 // the instantiation without it has no memory-table path in its deposit loop.
-// Dynamic LDS: per wave (64 * L + LP + 5 * 64) doubles.
+// Dynamic LDS: per wave (DRT_I_WORDS(L) + LP + 5 * DRT_BST + 3) doubles.
 template <int LP, bool BIG>
 __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
 {
@@ -609,15 +621,19 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     // then lives in scalar registers instead of 50+ vector registers that are spilled inside divergent code
     const int wib = first_lane_i((int)(threadIdx.x >> 6));
     const int gwave = blockIdx.x * waves_per_block + wib;
-    ldouble* Ilds = (ldouble*)lds_w + wib * (64 * L + LP + 5 * 64);
-    ldouble* ll = Ilds + 64 * L;
-    ldouble* bst = ll + LP;  // [5][64]: C, U of the wavelength being flushed; nx, ny, nz of every ray
+    ldouble* ll = (ldouble*)lds_w + wib * (DRT_I_WORDS(L) + LP + 5 * DRT_BST + 3) + DRT_I_WORDS(L);
+    ldouble* bst = ll + LP;  // [5][DRT_BST]: C, U of the wavelength being flushed; nx, ny, nz of every ray; 
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
     int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]
     int* hmem = hkey + a.hcap;                  // [4*hcap] sibling slots + [cap] per-entry codes
     int* ostat = hmem + 4ull * a.hcap + a.cap;  // [cap] status of parked rays / prefix weights
     double* thg = (double*)(((unsigned long long)(ostat + a.cap) + 15ull) & ~15ull);  // [L][64]
+#ifdef DRT_I_GLOBAL
+    iptr_t Ilds = thg + 64 * L;  // [L][64], see carve_arena
+#else
+    iptr_t Ilds = ll - DRT_I_WORDS(L);
+#endif
     const int G = a.sectors_per_task;
     const int tasks_per_src = 48 / G;
     const bool from_spawn = a.spawn_count > 0;
