@@ -525,26 +525,49 @@ static int ensure_arena(drt_ctx* c)
     return DRT_OK;
 }
 
-// Split the arena among the `waves` wavefronts of one launch. Per wave: 4 queues of `cap` rays
-// (high A/B, low, staging), a hash table of >= 2*cap slots (4 + 16 bytes each) and two int arrays.
-static int carve_arena(drt_ctx* c, int waves, StageArgs& a)
+// Split the arena among the `waves` wavefronts of one launch: the deepest queues (`cap` rays, a multiple of 64) whose
+// slices (arena_layout, rt_kernels.hpp) fit. Pure arithmetic, exported so that the layout can be checked without a GPU.
+#define DRT_MIN_CAP 64
+extern "C" int drt_arena_carve(size_t arena_bytes, int32_t waves, int32_t lp, int32_t* cap_out, int32_t* hcap_out, uint64_t* stride_out,
+                               uint64_t offsets[10])
 {
-    const unsigned long long per_ray = 4ull * (28 + 8ull * c->LP) + 4ull * 20 + 8 + 16;
-    unsigned long long cap = (c->arena_bytes / (unsigned long long)waves - 1024ull * c->LP - 272) / per_ray;
+    if (waves < 1 || lp < 1 || lp > DRT_MAXL || !cap_out || !hcap_out || !stride_out) return DRT_E_ARG;
+    const unsigned long long per_ray = 4ull * (28 + 8ull * lp) + 4ull * 20 + 8 + 16;  // lists + hash (2 entries per ray) + codes + status
+    const unsigned long long per_wave = arena_bytes / (unsigned long long)waves;
+    if (per_wave < 1024ull * lp + 272 + DRT_MIN_CAP * per_ray) return DRT_E_CAPACITY;
+    unsigned long long cap = (per_wave - 1024ull * lp - 272) / per_ray;
     if (cap > (1ull << 22)) cap = 1ull << 22;
     cap = cap / 64 * 64;
-    if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, waves);
-    int hcap = 64;
-    while (hcap < 2 * (int)cap) hcap <<= 1;
-    for (;;) {
-        unsigned long long stride = 4ull * list_bytes((int)cap, c->LP) + 20ull * hcap + 8ull * cap + 1024ull * c->LP + 16;  // ... + thg [L][64] + (DRT_I_GLOBAL) intensities [L][64]
-        stride = (stride + 255) / 256 * 256;
-        if (stride * (unsigned long long)waves <= c->arena_bytes) { a.cap = (int)cap; a.hcap = hcap; a.wave_stride = stride; break; }
-        cap -= 64;
-        if (cap < 256) return fail(c, DRT_E_ARG, "arena of %zu bytes too small for %d waves", c->arena_bytes, waves);
-        hcap = 64;
+    for (;; cap -= 64) {
+        if (cap < DRT_MIN_CAP) return DRT_E_CAPACITY;
+        int hcap = 64;
         while (hcap < 2 * (int)cap) hcap <<= 1;
+        const ArenaLayout L = arena_layout((int)cap, hcap, lp);
+        const unsigned long long stride = (L.end + 255) / 256 * 256;
+        if (stride * (unsigned long long)waves <= arena_bytes) {
+            *cap_out = (int32_t)cap; *hcap_out = hcap; *stride_out = stride;
+            if (offsets) {
+                for (int k = 0; k < 4; k++) offsets[k] = L.list[k];
+                offsets[4] = L.hkey; offsets[5] = L.hmem; offsets[6] = L.ostat; offsets[7] = L.thg; offsets[8] = L.inten; offsets[9] = L.end;
+            }
+            return DRT_OK;
+        }
     }
+}
+
+static int carve_arena(drt_ctx* c, int waves, StageArgs& a)
+{
+    int32_t cap = 0, hcap = 0;
+    uint64_t stride = 0;
+    if (drt_arena_carve(c->arena_bytes, waves, c->LP, &cap, &hcap, &stride, nullptr) != DRT_OK)
+        return fail(c, DRT_E_CAPACITY, "arena of %zu bytes too small for %d waves (fewer than %d rays per queue)", c->arena_bytes, waves, DRT_MIN_CAP);
+    // test aid: DRT_TEST_MAX_CAP shortens the queues (>= 16 rays) so that small cases exercise the overflow paths; the
+    // slices keep their stride, only less of each is used (>= 16 rays, >= 4 for one-sector tasks)
+    if (const char* e = getenv("DRT_TEST_MAX_CAP")) {
+        const int lim = std::max(a.sectors_per_task > 1 ? 16 : 4, atoi(e));  // a task starts with sectors_per_task rays in its queue
+        if (cap > lim) { cap = lim; hcap = 64; while (hcap < 2 * cap) hcap <<= 1; }
+    }
+    a.cap = cap; a.hcap = hcap; a.wave_stride = stride;
     c->cap = a.cap; c->hcap = a.hcap; c->wave_stride = a.wave_stride;
     return DRT_OK;
 }
@@ -848,6 +871,37 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         default: launch_stage<64>(c, a, nblocks); break;
         }
     };
+    // The accumulators this stage adds to are snapshotted (device-to-device, ~0.4 ms per GB): when a ray queue outgrows
+    // its wave's arena slice every wave stops at its next task (they poll the error word), the launch is undone and
+    // repeated with deeper queues - half the sectors per task for cell sources, half the waves for point sources.
+    const size_t NL = (size_t)c->N * c->L;
+    if (!c->d_bak_u) HIPCHK(c, hipMalloc((void**)&c->d_bak_u, NL * sizeof(double)));
+    if (!c->d_bak_lost) HIPCHK(c, hipMalloc((void**)&c->d_bak_lost, (size_t)c->L * sizeof(double)));
+    if (!c->d_bak_cnt) HIPCHK(c, hipMalloc((void**)&c->d_bak_cnt, CNT_N * sizeof(unsigned long long)));
+    if (direct && c->d_bak_scaspe.size() != (size_t)c->L) {
+        for (auto p : c->d_bak_scaspe) if (p) (void)hipFree(p);
+        c->d_bak_scaspe.assign(c->L, nullptr);
+        for (int il = 0; il < c->L; il++) HIPCHK(c, hipMalloc((void**)&c->d_bak_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
+    }
+    double* acc_u = precalc ? c->d_u_fest : c->d_u_final;
+    auto copy_state = [&](bool save) -> int {
+        auto cp = [&](void* bak, void* live, size_t bytes) { return save ? hipMemcpyAsync(bak, live, bytes, hipMemcpyDeviceToDevice, 0) : hipMemcpyAsync(live, bak, bytes, hipMemcpyDeviceToDevice, 0); };
+        HIPCHK(c, cp(c->d_bak_u, acc_u, NL * sizeof(double)));
+        HIPCHK(c, cp(c->d_bak_cnt, c->d_counters, CNT_N * sizeof(unsigned long long)));
+        if (direct) {
+            HIPCHK(c, cp(c->d_bak_lost, c->d_lum_lost, (size_t)c->L * sizeof(double)));
+            for (int il = 0; il < c->L; il++) HIPCHK(c, cp(c->d_bak_scaspe[il], c->d_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
+        }
+        return DRT_OK;
+    };
+    // device error word after a launch: 0, "queue overflow only" (recoverable: reset and report true), or something else
+    auto overflowed = [&](bool& ovf) -> int {
+        int e = 0;
+        HIPCHK(c, hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
+        ovf = (e & ERR_CAPACITY) && !(e & ~ERR_CAPACITY);
+        if (ovf) HIPCHK(c, hipMemset(c->d_error, 0, sizeof(int)));
+        return DRT_OK;
+    };
     HIPCHK(c, hipEventRecord(c->ev0, 0));
     if (psrc) {
         // few, deep sources: sub-tree tasks (StageArgs::export_level). Phase 1 exports at most 192 rays per source.
@@ -858,70 +912,65 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             HIPCHK(c, hipMalloc((void**)&c->d_spawn, list_bytes(need, c->LP) + 4ull * need));
         }
         if (!c->d_spawn_counter) HIPCHK(c, hipMalloc((void**)&c->d_spawn_counter, sizeof(int)));
-        HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
         a.spawn = c->d_spawn; a.spawn_cap = c->spawn_cap; a.spawn_counter = c->d_spawn_counter;
-        a.export_level = 4;
-        if ((rc = carve_arena(c, blocks * 4, a))) return rc;
-        HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-        launch(blocks);
-        int nspawn = 0;
-        HIPCHK(c, hipMemcpy(&nspawn, c->d_spawn_counter, sizeof(int), hipMemcpyDeviceToHost));
-        c->cnt.launches = 1;
-        if (nspawn > 0) {
-            a.export_level = 0; a.spawn_count = nspawn;
-            long long nt = 4ll * nspawn;
-            int blocks2 = (int)((nt + 3) / 4);
-            if (blocks2 > c->waves / 4) blocks2 = c->waves / 4;
-            if ((rc = carve_arena(c, blocks2 * 4, a))) return rc;
+        for (int max_blocks = c->waves / 4;; max_blocks = (max_blocks + 1) / 2) {
+            if ((rc = copy_state(true))) return rc;
+            HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
+            a.export_level = 4; a.spawn_count = 0;
+            const int blocks1 = std::max(1, std::min(blocks, max_blocks));
+            if ((rc = carve_arena(c, blocks1 * 4, a))) {  // not even 64-ray queues for this many waves: use fewer
+                if (rc == DRT_E_CAPACITY && blocks1 > 1) { max_blocks = blocks1; continue; }
+                return rc;
+            }
             HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-            launch(blocks2);
-            c->cnt.launches = 2;
+            HIPCHK(c, hipEventRecord(c->ev0, 0));
+            launch(blocks1);
+            c->cnt.launches++;
+            int nspawn = 0;
+            HIPCHK(c, hipMemcpy(&nspawn, c->d_spawn_counter, sizeof(int), hipMemcpyDeviceToHost));
+            bool ovf = false;
+            if ((rc = overflowed(ovf))) return rc;
+            int blocks2 = 0;
+            if (!ovf && nspawn > 0) {
+                a.export_level = 0; a.spawn_count = std::min(nspawn, c->spawn_cap);
+                const long long nt = 4ll * a.spawn_count;
+                blocks2 = (int)std::max(1ll, std::min((nt + 3) / 4, (long long)max_blocks));
+                while ((rc = carve_arena(c, blocks2 * 4, a)) == DRT_E_CAPACITY && blocks2 > 1) blocks2 = (blocks2 + 1) / 2;
+                if (rc) return rc;
+                HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+                launch(blocks2);
+                c->cnt.launches++;
+                if ((rc = overflowed(ovf))) return rc;
+            }
+            if (!ovf) break;
+            if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
+            if (max_blocks <= 1) return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
     } else {
-        // Cell sources: G sectors per task. More sectors fill the lanes better but lengthen the queues; how long they
-        // get depends on the grid. The accumulators this stage adds to are snapshotted, and when a queue outgrows its
-        // arena slice the launch is undone and repeated with half the sectors per task (waves stop at the first error).
-        const size_t NL = (size_t)c->N * c->L;
-        if (!c->d_bak_u) HIPCHK(c, hipMalloc((void**)&c->d_bak_u, NL * sizeof(double)));
-        if (!c->d_bak_lost) HIPCHK(c, hipMalloc((void**)&c->d_bak_lost, (size_t)c->L * sizeof(double)));
-        if (!c->d_bak_cnt) HIPCHK(c, hipMalloc((void**)&c->d_bak_cnt, CNT_N * sizeof(unsigned long long)));
-        if (direct && c->d_bak_scaspe.size() != (size_t)c->L) {
-            for (auto p : c->d_bak_scaspe) if (p) (void)hipFree(p);
-            c->d_bak_scaspe.assign(c->L, nullptr);
-            for (int il = 0; il < c->L; il++) HIPCHK(c, hipMalloc((void**)&c->d_bak_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
-        }
-        double* acc_u = precalc ? c->d_u_fest : c->d_u_final;
-        auto copy_state = [&](bool save) -> int {
-            auto cp = [&](void* bak, void* live, size_t bytes) { return save ? hipMemcpyAsync(bak, live, bytes, hipMemcpyDeviceToDevice, 0) : hipMemcpyAsync(live, bak, bytes, hipMemcpyDeviceToDevice, 0); };
-            HIPCHK(c, cp(c->d_bak_u, acc_u, NL * sizeof(double)));
-            HIPCHK(c, cp(c->d_bak_cnt, c->d_counters, CNT_N * sizeof(unsigned long long)));
-            if (direct) {
-                HIPCHK(c, cp(c->d_bak_lost, c->d_lum_lost, (size_t)c->L * sizeof(double)));
-                for (int il = 0; il < c->L; il++) HIPCHK(c, cp(c->d_bak_scaspe[il], c->d_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
-            }
-            return DRT_OK;
-        };
+        // Cell sources: G sectors per task. More sectors fill the lanes better (and merge more rays per atomic) but
+        // lengthen the queues; how long they get depends on the grid. The value that fitted is kept for the next call.
         int Gtry = c->G_cell > 0 ? std::min(c->G_cell, 16) : G;
+        int max_blocks = c->waves / 4;
         for (;;) {
             a.sectors_per_task = Gtry;
             ntasks = (long long)list.size() * (48 / Gtry);
-            blocks = (int)((ntasks + 3) / 4);
-            if (blocks > c->waves / 4) blocks = c->waves / 4;
+            blocks = (int)std::max(1ll, std::min((ntasks + 3) / 4, (long long)max_blocks));
+            if ((rc = carve_arena(c, blocks * 4, a))) {  // not even 64-ray queues for this many waves: use fewer
+                if (rc == DRT_E_CAPACITY && blocks > 1) { max_blocks = (blocks + 1) / 2; continue; }
+                return rc;
+            }
             if ((rc = copy_state(true))) return rc;
-            if ((rc = carve_arena(c, blocks * 4, a))) return rc;
             HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
             HIPCHK(c, hipEventRecord(c->ev0, 0));
             launch(blocks);
             c->cnt.launches++;
-            int e = 0;
-            HIPCHK(c, hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
-            if ((e & ERR_CAPACITY) && !(e & ~ERR_CAPACITY) && Gtry > 1) {
-                HIPCHK(c, hipMemset(c->d_error, 0, sizeof(int)));
-                if ((rc = copy_state(false))) return rc;
-                Gtry /= 2;
-                continue;
-            }
-            break;
+            bool ovf = false;
+            if ((rc = overflowed(ovf))) return rc;
+            if (!ovf) break;
+            if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
+            if (Gtry > 1) Gtry /= 2;                  // shorter queues first,
+            else if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;  // then fewer waves with deeper ones
+            else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
         c->G_cell = Gtry;
     }

@@ -60,6 +60,30 @@ __host__ __device__ inline unsigned long long list_bytes(int cap, int LP)
     return 12ull * cap + 4ull * (cap & 1) + 16ull * cap + 8ull * (unsigned long long)cap * LP;
 }
 
+// Layout of ONE wave's slice of the ray-queue arena (byte offsets from the slice's base). One definition for the kernels
+// that carve the slice and for the host that sizes it (carve_arena) - and for the test that checks that no region
+// overlaps the next and that the slice ends inside its stride (tests/test_abi.py).
+//   list[0..3]  SoA ray queues of `cap` rays: high A, high B, low, staging
+//   hkey        [hcap] int            sibling hash: parent pixel
+//   hmem        [4*hcap + cap] int    sibling slots of every hash entry, then one code per extracted ray
+//   ostat       [cap] int             status of parked rays / prefix weights
+//   thg         [LP][64] double       HG normalisation of every (wavelength, ray) of the ray-major kernel
+//   inten       [LP][64] double       ray intensities when they are not kept in LDS (-DDRT_I_GLOBAL)
+struct ArenaLayout { unsigned long long list[4], hkey, hmem, ostat, thg, inten, end; };
+__host__ __device__ inline ArenaLayout arena_layout(int cap, int hcap, int LP)
+{
+    ArenaLayout a;
+    const unsigned long long lb = list_bytes(cap, LP);
+    for (int k = 0; k < 4; k++) a.list[k] = (unsigned long long)k * lb;
+    a.hkey = 4ull * lb;
+    a.hmem = a.hkey + 4ull * (unsigned long long)hcap;
+    a.ostat = a.hmem + 4ull * (4ull * (unsigned long long)hcap + (unsigned long long)cap);
+    a.thg = (a.ostat + 4ull * (unsigned long long)cap + 15ull) & ~15ull;
+    a.inten = a.thg + 512ull * (unsigned long long)LP;
+    a.end = a.inten + 512ull * (unsigned long long)LP;
+    return a;
+}
+
 #define META(nsl, isel, type, merged) ((uint32_t)(nsl) | ((uint32_t)(isel) << 8) | ((uint32_t)(type) << 12) | ((uint32_t)(merged) << 16))
 #define META_NSL(m) ((int)((m) & 31u))
 #define META_ISEL(m) ((int)(((m) >> 8) & 3u))
@@ -925,9 +949,10 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
     const int gwave = blockIdx.x * waves_per_block + first_lane_i((int)(threadIdx.x >> 6));
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
-    int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]
-    int* hmem = hkey + a.hcap;                  // [4*hcap] sibling slots + [cap] per-entry codes
-    int* ostat = hmem + 4ull * a.hcap + a.cap;  // [cap] status of parked rays / prefix weights
+    const ArenaLayout AL = arena_layout(a.cap, a.hcap, LP);
+    int* hkey = (int*)(abase + AL.hkey);
+    int* hmem = (int*)(abase + AL.hmem);
+    int* ostat = (int*)(abase + AL.ostat);
     const int G = a.sectors_per_task;
     const int tasks_per_src = 48 / G;
     const bool from_spawn = a.spawn_count > 0;

@@ -625,12 +625,13 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     ldouble* bst = ll + LP;  // [5][DRT_BST]: C, U of the wavelength being flushed; nx, ny, nz of every ray; 
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
-    int* hkey = (int*)(abase + 4ull * lbytes);  // [hcap]
-    int* hmem = hkey + a.hcap;                  // [4*hcap] sibling slots + [cap] per-entry codes
-    int* ostat = hmem + 4ull * a.hcap + a.cap;  // [cap] status of parked rays / prefix weights
-    double* thg = (double*)(((unsigned long long)(ostat + a.cap) + 15ull) & ~15ull);  // [L][64]
+    const ArenaLayout AL = arena_layout(a.cap, a.hcap, LP);
+    int* hkey = (int*)(abase + AL.hkey);
+    int* hmem = (int*)(abase + AL.hmem);
+    int* ostat = (int*)(abase + AL.ostat);
+    double* thg = (double*)(abase + AL.thg);  // [L][64]
 #ifdef DRT_I_GLOBAL
-    iptr_t Ilds = thg + 64 * L;  // [L][64], see carve_arena
+    iptr_t Ilds = (double*)(abase + AL.inten);  // [L][64]
 #else
     iptr_t Ilds = ll - DRT_I_WORDS(L);
 #endif

@@ -46,7 +46,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve"]
 
 
 def build(force: bool = False) -> str:
@@ -96,12 +96,21 @@ def lib():
         L.drt_comm_unique_id.argtypes = [C.c_char_p]
         L.drt_comm_init.argtypes = [vp, i32, i32, C.c_char_p]
         L.drt_comm_destroy.argtypes = [vp]
+        L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def arena_carve(arena_bytes: int, waves: int, lp: int):
+    """drt_arena_carve: (cap, hcap, stride, offsets[10]) or None when the arena is too small. Needs no GPU."""
+    cap, hcap, stride = C.c_int32(), C.c_int32(), C.c_uint64()
+    off = (C.c_uint64 * 10)()
+    rc = lib().drt_arena_carve(arena_bytes, waves, lp, C.byref(cap), C.byref(hcap), C.byref(stride), off)
+    return None if rc != 0 else (cap.value, hcap.value, stride.value, list(off))
 
 
 class DartRayGPU:

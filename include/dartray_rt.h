@@ -149,6 +149,13 @@ int drt_calc_sed(drt_ctx *ctx, double *sed);
 int drt_get_counters(const drt_ctx *ctx, drt_counters *out);
 int drt_reset_counters(drt_ctx *ctx);
 
+/* Introspection (no GPU needed): how an arena of `arena_bytes` is split among `waves` wavefronts carrying `lp`
+ * (a power of two >= lnum) luminosities per ray: queue depth `cap`, hash size `hcap`, bytes per wave `stride`, and the
+ * byte offsets of the regions of one wave's slice: 4 ray queues, hash keys, hash members, status words, HG
+ * normalisations, intensities, end. DRT_E_CAPACITY when fewer than 64 rays per queue would fit. */
+int drt_arena_carve(size_t arena_bytes, int32_t waves, int32_t lp, int32_t *cap, int32_t *hcap, uint64_t *stride,
+                    uint64_t offsets[10]);
+
 /* ---- multi-GPU (one process per GPU; rt_mpi's MPI_Allreduce becomes ncclAllReduce over xGMI) ---- */
 #define DRT_UNIQUE_ID_BYTES 128
 int drt_comm_unique_id(char id[DRT_UNIQUE_ID_BYTES]);

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,3 +94,29 @@ def test_config_builders_keep_the_reference_layout():
             assert np.allclose(t.ccoord[kids], want, rtol=0, atol=1e-9 * t.modelsize)
         assert ((case.dens_stars.sum(axis=1) > 0) <= t.leaf).all()
         assert np.isfinite(case.dens).all() and (case.dens >= 0).all()
+
+
+def test_arena_layout_regions_do_not_overlap(pkg):
+    """carve_arena's arithmetic (drt_arena_carve, no GPU needed): for every split of an arena among waves the regions
+    of one wave's slice - four SoA ray queues, sibling hash, status words, HG normalisations [LP][64], intensities
+    [LP][64] - follow each other without overlap, end inside the wave's stride, and all strides fit the arena. A
+    queue overflow must therefore surface as DRT_E_CAPACITY, never as a write into a neighbour's slice."""
+    rng = np.random.default_rng(7)
+    cases = [(16 << 30, 2048, 32), (128 << 30, 4096, 32), (1 << 30, 1024, 1), (64 << 20, 256, 4), (9 << 20, 256, 2)]
+    cases += [(int(rng.integers(1 << 20, 1 << 34)), int(rng.integers(1, 1025)) * 4, int(2 ** rng.integers(0, 7))) for _ in range(200)]
+    seen_ok = 0
+    for arena, waves, lp in cases:
+        r = pkg.host.arena_carve(arena, waves, lp)
+        if r is None:
+            continue
+        seen_ok += 1
+        cap, hcap, stride, off = r
+        assert cap >= 64 and cap % 64 == 0 and hcap >= 2 * cap and (hcap & (hcap - 1)) == 0
+        assert stride * waves <= arena and stride % 256 == 0
+        lb = 12 * cap + 16 * cap + 8 * cap * lp          # one SoA queue: ipix, meta, cc | prev, dpl | lum[LP]
+        sizes = [lb, lb, lb, lb, 4 * hcap, 4 * (4 * hcap + cap), 4 * cap, 512 * lp, 512 * lp]
+        for k in range(9):
+            assert off[k] + sizes[k] <= off[k + 1], (arena, waves, lp, k)
+        assert off[7] % 16 == 0 and off[9] <= stride
+    assert seen_ok > 50
+    assert pkg.host.arena_carve(1 << 20, 4096, 32) is None  # too small: an error, not a layout

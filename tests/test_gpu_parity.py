@@ -81,6 +81,98 @@ def test_gpu_matches_reference_golden(name, mapping, golden, pkg, monkeypatch):
     g.close()
 
 
+def _arena_for_cap(pkg, waves, lp, want_cap):
+    """Smallest arena (in 64 KiB steps) that gives `waves` wavefronts queues of at least want_cap rays."""
+    a = 64 << 10
+    while True:
+        r = pkg.host.arena_carve(a, waves, lp)
+        if r is not None and r[0] >= want_cap:
+            return a
+        a += 64 << 10
+
+
+@pytest.mark.parametrize("name", ["blobB", "blobD"])
+def test_queue_overflow_is_undone_and_retried(name, golden, pkg):
+    """An arena that gives 16 waves ray queues of 512 rays (256 waves: 32, below the minimum of 64): the cell-source stages overflow at 16, 8, ... sectors per
+    task and the point-source stages at full width. Every overflowing launch must be undone (accumulators, counters, lum_lost,
+    scaspe restored from the snapshot) and repeated with deeper queues - fewer sectors per task for cell sources,
+    fewer waves for point sources - and the end result must still equal the reference's golden vectors."""
+    z, path = golden(name)
+    case = pkg.grids.read_case(path, name)
+    lp = 1
+    while lp < case.lnum:
+        lp *= 2
+    # room for 64-ray queues of 16 waves, 256 waves asked for: the library must also come down in waves by itself
+    g = pkg.DartRayGPU(case, arena_bytes=_arena_for_cap(pkg, 16, lp, 512), waves=256)
+    launches = {}
+    g.rt_prepare("start")
+    for rt in ("precalc_cell", "precalc_src"):
+        g.rt_loop(rt); launches[rt] = g.counters()["launches"]
+    g.rt_mpi("precalc_src")
+    assert relmax(g.u_fest, z["u_fest"]) <= RTOL
+    g.rt_prepare("prep_part2")
+    for rt in ("dir_cell", "dir_src"):
+        g.rt_loop(rt); launches[rt] = g.counters()["launches"]
+    g.rt_mpi("dir_src")
+    assert launches["dir_cell"] > 1, launches     # at least one undo + retry with fewer sectors per task
+    assert relmax(g.u_final, z["u_final_dir"]) <= RTOL and relelem(g.u_final, z["u_final_dir"]) <= RTOL_ELEM
+    assert relmax(g.lum_lost, z["lum_lost_dir"]) <= 1e-7
+    for il in range(g.L):
+        golden_scaspe_check(z, "scaspe_dir", il, g.scaspe(il), RTOL, name, RTOL_ELEM)
+    while not g.scatt_prepare():
+        g.rt_loop("scatt"); g.rt_mpi("scatt")
+    assert g.iterations == int(z["iterations"])
+    assert relmax(g.u_final, z["u_final"]) <= RTOL and relelem(g.u_final, z["u_final"]) <= RTOL_ELEM
+    assert relmax(g.lum_lost, z["lum_lost"]) <= 1e-7
+    for il in range(g.L):
+        golden_scaspe_check(z, "scaspe_tot", il, g.scaspe_tot(il), RTOL, name, RTOL_ELEM)
+    g.close()
+
+
+def test_point_source_overflow_is_a_clean_capacity_error(golden, pkg, monkeypatch):
+    """Sub-tree tasks of a point source with 4-ray queues (DRT_TEST_MAX_CAP, a test aid of carve_arena; with the 64 rays
+    of the smallest real arena the sub-tree ladders of the test cases never overflow): the
+    direct-light stage of the TRUST-I case overflows in every attempt. Each attempt must be undone, the stage must end
+    in DRT_E_CAPACITY with the accumulators as they were - the failure mode of round 1 was a memory fault - and with
+    full-depth queues the same context must then reproduce the golden result."""
+    z, path = golden("slab1801")
+    case = pkg.grids.read_case(path, "slab1801")
+    g = pkg.DartRayGPU(case, waves=64)
+    g.rt_prepare("start")
+    g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+    g.rt_prepare("prep_part2")
+    g.rt_loop("dir_cell")
+    monkeypatch.setenv("DRT_TEST_MAX_CAP", "4")
+    with pytest.raises(pkg.host.DartRayError, match="-5"):
+        g.rt_loop("dir_src")
+    assert g.counters()["launches"] > 2   # more than one attempt (phase 1 + phase 2 each)
+    assert float(np.abs(g.u_final).max()) == 0.0 and float(np.abs(g.scaspe(0)).max()) == 0.0 and float(g.lum_lost.max()) == 0.0
+    monkeypatch.delenv("DRT_TEST_MAX_CAP")
+    g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+    assert relmax(g.u_final, z["u_final_dir"]) <= RTOL
+    golden_scaspe_check(z, "scaspe_dir", 0, g.scaspe(0), RTOL, "slab1801", RTOL_ELEM)
+    g.close()
+
+
+def test_hopeless_arena_is_a_clean_capacity_error(golden, pkg):
+    """One block of four waves with 64-ray queues cannot hold blobB's direct-light ladders even at one sector per task:
+    the stage must come back as DRT_E_CAPACITY (-5) with the accumulators untouched - not as a memory fault - and the
+    context must go on working once it is given room."""
+    z, path = golden("blobB")
+    case = pkg.grids.read_case(path, "blobB")
+    g = pkg.DartRayGPU(case, arena_bytes=_arena_for_cap(pkg, 4, 4, 64), waves=4)
+    g.rt_prepare("start")
+    g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+    g.rt_prepare("prep_part2")
+    with pytest.raises(pkg.host.DartRayError, match="-5"):
+        g.rt_loop("dir_cell")
+    assert float(np.abs(g.u_final).max()) == 0.0 and all(float(np.abs(g.scaspe(il)).max()) == 0.0 for il in range(g.L))
+    g.L_.drt_configure(g.h, 1 << 30, 1024)
+    g.rt_loop("dir_cell"); g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+    assert relmax(g.u_final, z["u_final_dir"]) <= RTOL
+    g.close()
+
+
 @pytest.mark.parametrize("name", ["blobA", "blobD", "trusti32"])
 def test_gpu_counters_match_oracle(name, golden, pkg):
     """Intersections / rays / deposits are the reference's own definitions: the GPU
