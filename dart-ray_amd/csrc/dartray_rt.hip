@@ -284,6 +284,7 @@ extern "C" int drt_set_params(drt_ctx* c, const drt_params* p)
     if (p->np_mpi < 1 || p->id_mpi < 0 || p->id_mpi >= p->np_mpi) return fail(c, DRT_E_ARG, "drt_set_params: bad np_mpi/id_mpi");
     if (p->bm_par <= 0 || p->bm_par_sca <= 0 || p->bm_par_max <= 0) return fail(c, DRT_E_ARG, "drt_set_params: bm_par* must be positive");
     if (p->kp_sca_max < 0 || p->kp_sca_max > 4) return fail(c, DRT_E_ARG, "drt_set_params: kp_sca_max outside [0,4] (check_input, io_routines.f90:2745)");
+    if (c->comm && (p->np_mpi != c->nranks || p->id_mpi != c->rank)) return fail(c, DRT_E_ARG, "drt_set_params: np_mpi/id_mpi differ from the communicator's size/rank");
     c->par = *p; c->have_par = true; c->bm_par_cur = p->bm_par; c->prepared = false;
     return DRT_OK;
 }
@@ -754,20 +755,48 @@ extern "C" int drt_rt_prepare(drt_ctx* c, int32_t rt_type)
 }
 
 // ---- rt_loop ---------------------------------------------------------------------------------------------
+// The sources of one rt_loop call on this rank. Cell sources are shared among the ranks in CHUNKS of consecutive
+// emitting cells dealt round the ranks (block-cyclic; DRT_PARTITION_CHUNK cells per chunk, default 64).
+// Sums over sources commute, so every deal gives the same fields after rt_mpi; what differs is speed (measured on the
+// bench workload with 8 ranks, tools/partition_ab.py):
+//  * the reference's deal, every np-th cell (i = im*np_mpi + id_mpi, rt_routines.f90:1003-1005; DRT_PARTITION=mod),
+//    balances well but a rank's sources are no longer neighbours: they stop sharing tree, density and scaspe lines in
+//    the caches and the SUM of the ranks' times grows by 40 % at 32 wavelengths and 5.4x at one;
+//  * one contiguous block per rank (DRT_PARTITION=block) keeps the locality but the cost of a source varies with its
+//    place in the model - the slowest rank had 3.9x the mean work;
+//  * chunks keep neighbours together (a GPU has ~170 sources in flight at once) and sample the whole model.
+// Point sources are not shared here: every rank takes all of them and the ranks split their (source, sector) tasks
+// instead (StageArgs::task_first/task_stride). rt_loop_iobs runs on the main rank only (rt_routines.f90:1483, :1498).
 static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list)
 {
     const int N = c->N, L = c->L, np = c->par.np_mpi, id = c->par.id_mpi;
     list.clear();
     const bool psrc = (rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC || rt_type == DRT_RTT_I_OBS_DIR_SRC);
     const bool iobs = (rt_type == DRT_RTT_I_OBS_DIR_CELL || rt_type == DRT_RTT_I_OBS_DIR_SRC || rt_type == DRT_RTT_I_OBS);
+    const char* pe = getenv("DRT_PARTITION");
+    const bool by_mod = pe && !strcmp(pe, "mod"), by_block = pe && !strcmp(pe, "block");
+    size_t chunk = 64;
+    if (const char* ce = getenv("DRT_PARTITION_CHUNK")) chunk = (size_t)std::max(1, atoi(ce));
     for (int i = 0; i < N; i++) {
-        if (!iobs && (i % np) != id) continue;  // i = im*np_mpi + id_mpi (rt_routines.f90:1005); rt_loop_iobs has no split (:1498)
         if (c->cchild[i] != -1) continue;
         double s = 0;
         if (psrc) { if (c->src_cell[i] != -1) for (int il = 0; il < L; il++) s += c->p_src_lum[(size_t)c->src_cell[i] * L + il]; }
         else for (int il = 0; il < L; il++) s += c->lumcell_h[(size_t)i * L + il];
         if (s == 0) continue;  // rt_routines.f90:1016
+        if (!iobs && !psrc && by_mod && (i % np) != id) continue;
         list.push_back(i);
+    }
+    if (!iobs && !psrc && !by_mod && np > 1) {
+        const size_t n = list.size();
+        std::vector<int> mine;
+        if (by_block) {
+            const size_t lo = n * (size_t)id / np, hi = n * (size_t)(id + 1) / np;
+            mine.assign(list.begin() + lo, list.begin() + hi);
+        } else {
+            for (size_t k0 = (size_t)id * chunk; k0 < n; k0 += (size_t)np * chunk)
+                mine.insert(mine.end(), list.begin() + k0, list.begin() + std::min(n, k0 + chunk));
+        }
+        list.swap(mine);
     }
     if (list.size() > c->src_list_cap || !c->d_src_list) {
         if (c->d_src_list) (void)hipFree(c->d_src_list);
@@ -846,6 +875,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     int blocks = (int)((ntasks + 3) / 4);
     if (blocks > c->waves / 4) blocks = c->waves / 4;
     a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
+    a.task_first = 0; a.task_stride = 1;
     auto launch = [&](int nblocks) {
         if (c->ray_major) {
             switch (c->LP) {
@@ -917,6 +947,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if ((rc = copy_state(true))) return rc;
             HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
             a.export_level = 4; a.spawn_count = 0;
+            a.task_first = c->par.id_mpi; a.task_stride = c->par.np_mpi;  // the sector tasks of phase 1 are dealt round the ranks
             const int blocks1 = std::max(1, std::min(blocks, max_blocks));
             if ((rc = carve_arena(c, blocks1 * 4, a))) {  // not even 64-ray queues for this many waves: use fewer
                 if (rc == DRT_E_CAPACITY && blocks1 > 1) { max_blocks = blocks1; continue; }
@@ -933,6 +964,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             int blocks2 = 0;
             if (!ovf && nspawn > 0) {
                 a.export_level = 0; a.spawn_count = std::min(nspawn, c->spawn_cap);
+                a.task_first = 0; a.task_stride = 1;  // phase 2 runs what THIS rank exported
                 const long long nt = 4ll * a.spawn_count;
                 blocks2 = (int)std::max(1ll, std::min((nt + 3) / 4, (long long)max_blocks));
                 while ((rc = carve_arena(c, blocks2 * 4, a)) == DRT_E_CAPACITY && blocks2 > 1) blocks2 = (blocks2 + 1) / 2;
@@ -950,6 +982,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // Cell sources: G sectors per task. More sectors fill the lanes better (and merge more rays per atomic) but
         // lengthen the queues; how long they get depends on the grid. The value that fitted is kept for the next call.
         int Gtry = c->G_cell > 0 ? std::min(c->G_cell, 16) : G;
+        if (const char* e = getenv("DRT_SECTORS_PER_TASK")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = std::min(Gtry, v); }
         int max_blocks = c->waves / 4;
         for (;;) {
             a.sectors_per_task = Gtry;
@@ -1049,6 +1082,9 @@ extern "C" int drt_comm_unique_id(char id[DRT_UNIQUE_ID_BYTES])
 extern "C" int drt_comm_init(drt_ctx* c, int32_t nranks, int32_t rank, const char id[DRT_UNIQUE_ID_BYTES])
 {
     if (!c || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, DRT_E_ARG, "drt_comm_init: bad argument");
+    if (!c->have_par) return fail(c, DRT_E_ARG, "drt_comm_init: call drt_set_params first");
+    if (nranks != c->par.np_mpi || rank != c->par.id_mpi)
+        return fail(c, DRT_E_ARG, "drt_comm_init: nranks/rank (%d/%d) differ from np_mpi/id_mpi (%d/%d) of drt_set_params", nranks, rank, c->par.np_mpi, c->par.id_mpi);
     c->nranks = nranks; c->rank = rank;
     if (nranks == 1) return DRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1074,7 +1110,7 @@ extern "C" int drt_comm_destroy(drt_ctx* c)
 
 static int allreduce_sum(drt_ctx* c, double* d, size_t n)
 {
-    if (c->nranks == 1) return DRT_OK;
+    if (c->par.np_mpi == 1) return DRT_OK;
     nccl_allreduce_t f = (nccl_allreduce_t)rccl_sym("ncclAllReduce");
     if (!f || !c->comm) return fail(c, DRT_E_COMM, "drt_rt_mpi: np_mpi > 1 but no communicator (drt_comm_init)");
     int r = f(d, d, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, 0);
@@ -1086,6 +1122,10 @@ static int allreduce_sum(drt_ctx* c, double* d, size_t n)
 extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
 {
     if (!c || !c->prepared) return fail(c, DRT_E_ARG, "drt_rt_mpi: not prepared");
+    // the sources were shared according to np_mpi/id_mpi (drt_set_params): without a matching communicator the fields
+    // of this rank are partial sums and must not be passed on as results
+    if (c->par.np_mpi > 1 && (!c->comm || c->nranks != c->par.np_mpi || c->rank != c->par.id_mpi))
+        return fail(c, DRT_E_COMM, "drt_rt_mpi: np_mpi = %d but no communicator of that size (drt_comm_init)", c->par.np_mpi);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t NL = (size_t)c->N * c->L;
     int rc;
@@ -1099,8 +1139,8 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
         // reduce_scaspe_arr (:3806-3834), one wavelength at a time
         for (int il = 0; il < c->L; il++) if ((rc = allreduce_sum(c, c->d_scaspe[il], (size_t)c->N * c->npix[il]))) return rc;
         // reduce_lum_lost (:3837-3855)
-        if (rt_type == DRT_RTT_SCATT && c->nranks > 1)
-            hipLaunchKernelGGL(k_scale_sub, dim3(1), dim3(64), 0, 0, c->d_lum_lost, c->d_lum_lost_prev, (c->nranks - 1.0) / c->nranks, c->L);
+        if (rt_type == DRT_RTT_SCATT && c->par.np_mpi > 1)
+            hipLaunchKernelGGL(k_scale_sub, dim3(1), dim3(64), 0, 0, c->d_lum_lost, c->d_lum_lost_prev, (c->par.np_mpi - 1.0) / c->par.np_mpi, c->L);
         if ((rc = allreduce_sum(c, c->d_lum_lost, (size_t)c->L))) return rc;
     } else return fail(c, DRT_E_ARG, "drt_rt_mpi: rt_type %d has no reduction (io_routines.f90:3697)", rt_type);
     HIPCHK(c, hipDeviceSynchronize());
@@ -1205,6 +1245,19 @@ extern "C" int drt_get_src_cell(const drt_ctx* c, int32_t* src_cell, double* cco
     return DRT_OK;
 }
 
+// The cells this rank would trace in drt_rt_loop / drt_rt_loop_iobs(rt_type), in launch order.
+extern "C" int drt_get_sources(drt_ctx* c, int32_t rt_type, int32_t* out, int32_t capacity, int32_t* count)
+{
+    if (!c || !c->prepared || !count) return fail(c, DRT_E_ARG, "drt_get_sources: not prepared");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int> list;
+    int rc = build_src_list(c, rt_type, list);
+    if (rc) return rc;
+    *count = (int32_t)list.size();
+    if (out) for (int i = 0; i < (int)list.size() && i < capacity; i++) out[i] = list[i];
+    return DRT_OK;
+}
+
 extern "C" double drt_en_lim(const drt_ctx* c) { return c ? c->en_lim : 0.0; }
 extern "C" int32_t drt_iterations(const drt_ctx* c) { return c ? c->iterations : -1; }
 extern "C" int32_t drt_cnflag(const drt_ctx* c) { return c ? c->cnflag : -1; }
@@ -1258,6 +1311,14 @@ extern "C" int drt_debug_trace(drt_ctx* c, int capacity, int* out, int* count)
         HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(int)));
     }
     if (c->prepared) return upload_problem(c);
+    return DRT_OK;
+}
+
+// Developer aid: change the share of the sources this context traces without preparing it again (tools/partition_ab.py)
+extern "C" int drt_debug_set_rank(drt_ctx* c, int np_mpi, int id_mpi)
+{
+    if (!c || np_mpi < 1 || id_mpi < 0 || id_mpi >= np_mpi) return DRT_E_ARG;
+    c->par.np_mpi = np_mpi; c->par.id_mpi = id_mpi;
     return DRT_OK;
 }
 

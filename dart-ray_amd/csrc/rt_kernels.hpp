@@ -32,6 +32,9 @@ struct StageArgs {
     char* spawn;        // records: SoA list of spawn_cap rays + int src[spawn_cap]
     int spawn_cap;
     int* spawn_counter;
+    // Several ranks share the (source, sector) tasks of a point-source stage: this rank runs the tasks
+    // task_first + k * task_stride (rt_routines.f90:1356-1358: the 48 sectors of a source are independent)
+    int task_first, task_stride;
 };
 
 struct ListView {
@@ -976,7 +979,7 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
 
     for (;;) {
         int task = 0;
-        if (lane == 0) task = __atomic_load_n(P.error, __ATOMIC_RELAXED) ? 0x7fffffff : atomicAdd(P.task_counter, 1);  // stop at the first error anywhere
+        if (lane == 0) task = __atomic_load_n(P.error, __ATOMIC_RELAXED) ? 0x7fffffff : a.task_first + a.task_stride * atomicAdd(P.task_counter, 1);  // stop at the first error anywhere
         task = first_lane_i(task);
         if (task >= ntasks) break;
         const int nc = from_spawn ? spawn_src[task >> 2] : a.src_list[task / tasks_per_src];

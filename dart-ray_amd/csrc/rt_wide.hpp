@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
 
     for (;;) {
         int task = 0;
-        if (lane == 0) task = __atomic_load_n(P.error, __ATOMIC_RELAXED) ? 0x7fffffff : atomicAdd(P.task_counter, 1);  // stop at the first error anywhere
+        if (lane == 0) task = __atomic_load_n(P.error, __ATOMIC_RELAXED) ? 0x7fffffff : a.task_first + a.task_stride * atomicAdd(P.task_counter, 1);  // stop at the first error anywhere
         task = first_lane_i(task);
         if (task >= ntasks) break;
         const int nc = from_spawn ? spawn_src[task >> 2] : a.src_list[task / tasks_per_src];

@@ -149,6 +149,27 @@ module dartray_c
        type(c_ptr), value :: ctx
        type(drt_counters), intent(out) :: cnt
      end function drt_get_counters
+     integer(c_int) function drt_get_sources(ctx, rt_type, cells, capacity, count) bind(C, name='drt_get_sources')
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: rt_type, capacity
+       integer(c_int32_t), intent(out) :: cells(*), count
+     end function drt_get_sources
+     ! multi-GPU: one rank per GPU, rt_mpi's MPI_Allreduce becomes ncclAllReduce (RCCL over xGMI) on the device buffers
+     integer(c_int) function drt_comm_unique_id(id) bind(C, name='drt_comm_unique_id')
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: id(128)
+     end function drt_comm_unique_id
+     integer(c_int) function drt_comm_init(ctx, nranks, rank, id) bind(C, name='drt_comm_init')
+       import :: c_ptr, c_int, c_int32_t, c_char
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nranks, rank
+       character(kind=c_char), intent(in) :: id(128)
+     end function drt_comm_init
+     integer(c_int) function drt_comm_destroy(ctx) bind(C, name='drt_comm_destroy')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function drt_comm_destroy
   end interface
 end module dartray_c
 
@@ -247,6 +268,19 @@ contains
     call gpu_check(drt_set_array(gpu_ctx, DRT_A_DENS, 0, dens_arr, n), 'dens_arr')
     call gpu_check(drt_set_array(gpu_ctx, DRT_A_DENS_STARS, 0, dens_stars_arr, n), 'dens_stars_arr')
   end subroutine gpu_grid_initialize
+
+  !> np_mpi > 1: create the RCCL communicator rt_mpi reduces over. `id` is the 128-byte unique id that the main rank
+  !> obtained with gpu_comm_unique_id and broadcast (MPI_Bcast of 128 MPI_BYTE after initialize_mpi,
+  !> io_routines.f90:3610); np_mpi / id_mpi are the ones gpu_grid_initialize passed to drt_set_params.
+  subroutine gpu_comm_unique_id(id)
+    character(kind=c_char), intent(out) :: id(128)
+    call gpu_check(drt_comm_unique_id(id), 'drt_comm_unique_id')
+  end subroutine gpu_comm_unique_id
+
+  subroutine gpu_comm_init(id)
+    character(kind=c_char), intent(in) :: id(128)
+    call gpu_check(drt_comm_init(gpu_ctx, int(np_mpi, c_int32_t), int(id_mpi, c_int32_t), id), 'drt_comm_init')
+  end subroutine gpu_comm_init
 
   !> rt_prepare (dartray_hub.f90:386-469) for the cases that touch the path.
   subroutine rt_prepare()

@@ -46,7 +46,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources"]
 
 
 def build(force: bool = False) -> str:
@@ -96,6 +96,7 @@ def lib():
         L.drt_comm_unique_id.argtypes = [C.c_char_p]
         L.drt_comm_init.argtypes = [vp, i32, i32, C.c_char_p]
         L.drt_comm_destroy.argtypes = [vp]
+        L.drt_get_sources.argtypes = [vp, i32, ip, i32, ip]
         L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
@@ -202,12 +203,17 @@ class DartRayGPU:
             self._chk(self.L_.drt_rt_mpi(self.h, rt))
             return
         from . import parallel
+        parallel.rt_mpi(rt, self.mpi_fields(rt), self.group)
+
+    def mpi_fields(self, rt):
+        """The device buffers rt_mpi reduces for this stage, as zero-copy torch tensors."""
+        rt = RTT[rt] if isinstance(rt, str) else rt
         fields = {"u_fest": self.device_tensor("u_fest"), "u_final": self.device_tensor("u_final")}
         if rt != RTT["precalc_src"]:
             fields["lum_lost"] = self.device_tensor("lum_lost")
             fields["lum_lost_prev"] = self.device_tensor("lum_lost_prev")
             fields["scaspe"] = [self.device_tensor("scaspe", il) for il in range(self.L)]
-        parallel.rt_mpi(rt, fields, self.group)
+        return fields
 
     def attach_process_group(self, group=None):
         """Use an initialised torch.distributed group (backend nccl = RCCL) for the stage-end reductions."""
@@ -299,6 +305,15 @@ class DartRayGPU:
         out = np.zeros((max(self.ndir, 1), self.L))
         self._chk(self.L_.drt_calc_sed(self.h, _dp(out)))
         return out[: self.ndir]
+
+    def sources(self, rt) -> np.ndarray:
+        """Cells this rank traces in rt_loop(rt) (drt_get_sources)."""
+        rt = RTT[rt] if isinstance(rt, str) else rt
+        n = C.c_int32()
+        self._chk(self.L_.drt_get_sources(self.h, rt, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._chk(self.L_.drt_get_sources(self.h, rt, out.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)))
+        return out[: n.value]
 
     def counters(self) -> Dict[str, float]:
         c = Counters()

@@ -17,47 +17,58 @@ import torch.distributed as dist
 RTT_PRECALC_SRC, RTT_DIR_SRC, RTT_SCATT = 2, 7, 10
 
 
-def reduce_u_fest(u_fest: torch.Tensor, group=None) -> None:
-    """reduce_u_fest_arr (io_routines.f90:3708-3729): MPI_Reduce(SUM) + MPI_Bcast == all-reduce."""
-    dist.all_reduce(u_fest, op=dist.ReduceOp.SUM, group=group)
-
-
-def reduce_u_final(u_final: torch.Tensor, u_fest: torch.Tensor, rt_type: int, group=None) -> None:
-    """reduce_u_final_arr (io_routines.f90:3732-3761). In a scattering iteration every rank starts from
-    the same u_fest = u_final of the previous stage, so only the increments are summed."""
-    if rt_type == RTT_SCATT:
-        u_final.sub_(u_fest).clamp_(min=0.0)
-    dist.all_reduce(u_final, op=dist.ReduceOp.SUM, group=group)
-    if rt_type == RTT_SCATT:
-        u_final.add_(u_fest)
-
-
-def reduce_scaspe(scaspe: List[torch.Tensor], group=None) -> None:
-    """reduce_scaspe_arr (io_routines.f90:3806-3834): one wavelength at a time."""
-    for s in scaspe:
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-
-
-def reduce_lum_lost(lum_lost: torch.Tensor, lum_lost_prev: torch.Tensor, rt_type: int, group=None) -> None:
-    """reduce_lum_lost (io_routines.f90:3837-3855): lum_lost enters a scattering iteration holding the
-    global value on every rank, hence the (np-1)/np correction before the sum."""
-    npr = dist.get_world_size(group)
-    if rt_type == RTT_SCATT:
-        lum_lost.sub_(lum_lost_prev * ((npr - 1.0) / npr))
-    dist.all_reduce(lum_lost, op=dist.ReduceOp.SUM, group=group)
+def _steps(rt_type: int, f: Dict[str, object], npr: int):
+    """rt_mpi (io_routines.f90:3667-3704) as a list of (tensor to sum over the ranks, what to do afterwards): the
+    arithmetic in front of each sum is applied here, in place. One list per rank; the lists of all ranks line up."""
+    steps = []
+    if rt_type == RTT_PRECALC_SRC:
+        # reduce_u_fest_arr (:3708-3729): MPI_Reduce(SUM) + MPI_Bcast == all-reduce
+        steps.append((f["u_fest"], None))
+    elif rt_type in (RTT_DIR_SRC, RTT_SCATT):
+        # reduce_u_final_arr (:3732-3761): in a scattering iteration every rank starts from the same u_fest = u_final of
+        # the previous stage, so only the increments are summed
+        u_final, u_fest = f["u_final"], f["u_fest"]
+        if rt_type == RTT_SCATT:
+            u_final.sub_(u_fest).clamp_(min=0.0)
+            steps.append((u_final, lambda: u_final.add_(u_fest)))
+        else:
+            steps.append((u_final, None))
+        # reduce_scaspe_arr (:3806-3834): one wavelength at a time
+        for s in f["scaspe"]:
+            steps.append((s, None))
+        # reduce_lum_lost (:3837-3855): lum_lost enters a scattering iteration holding the global value on every rank,
+        # hence the (np-1)/np correction before the sum
+        if rt_type == RTT_SCATT:
+            f["lum_lost"].sub_(f["lum_lost_prev"] * ((npr - 1.0) / npr))
+        steps.append((f["lum_lost"], None))
+    else:
+        raise ValueError(f"rt_mpi: rt_type {rt_type} has no reduction (io_routines.f90:3697)")
+    return steps
 
 
 def rt_mpi(rt_type: int, fields: Dict[str, object], group=None) -> None:
-    """rt_mpi (io_routines.f90:3667-3704). `fields`: u_fest, u_final, lum_lost, lum_lost_prev (tensors)
-    and scaspe (list of tensors), all updated in place."""
-    if rt_type == RTT_PRECALC_SRC:
-        reduce_u_fest(fields["u_fest"], group)
-    elif rt_type in (RTT_DIR_SRC, RTT_SCATT):
-        reduce_u_final(fields["u_final"], fields["u_fest"], rt_type, group)
-        reduce_scaspe(fields["scaspe"], group)
-        reduce_lum_lost(fields["lum_lost"], fields["lum_lost_prev"], rt_type, group)
-    else:
-        raise ValueError(f"rt_mpi: rt_type {rt_type} has no reduction (io_routines.f90:3697)")
+    """rt_mpi over torch.distributed (backend nccl = RCCL on the GPU buffers, gloo on CPU tensors). `fields`: u_fest,
+    u_final, lum_lost, lum_lost_prev (tensors) and scaspe (list of tensors) of THIS rank, all updated in place."""
+    for t, after in _steps(rt_type, fields, dist.get_world_size(group)):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if after:
+            after()
+
+
+def rt_mpi_local(rt_type: int, rank_fields: List[Dict[str, object]]) -> None:
+    """The same reductions for several ranks that live in ONE process (e.g. two library contexts on one GPU, each with
+    its own id_mpi): the all-reduce is a sum over the list. Used to test the product's multi-rank path - source
+    partition, device-buffer aliasing, the arithmetic around the sums - where only one GPU is available."""
+    npr = len(rank_fields)
+    per_rank = [_steps(rt_type, f, npr) for f in rank_fields]
+    for k in range(len(per_rank[0])):
+        total = per_rank[0][k][0].clone()
+        for r in range(1, npr):
+            total.add_(per_rank[r][k][0])
+        for r in range(npr):
+            per_rank[r][k][0].copy_(total)
+            if per_rank[r][k][1]:
+                per_rank[r][k][1]()
 
 
 class _DevAlias:

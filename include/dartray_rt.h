@@ -147,6 +147,11 @@ int32_t drt_cnflag(const drt_ctx *ctx);
 /* calc_sed + sum_i_obs for units 'erg/s/Hz/pc^2/sr' (sed_routines.f90:90-146, 211-246): sed(lnum,tot_ndir) */
 int drt_calc_sed(drt_ctx *ctx, double *sed);
 int drt_get_counters(const drt_ctx *ctx, drt_counters *out);
+/* The cells THIS rank traces in drt_rt_loop / drt_rt_loop_iobs(rt_type) - the loop `i = im*np_mpi + id_mpi` of
+ * rt_routines.f90:1003-1016 after its skips (parents, zero luminosity). Cell sources are shared among the np_mpi ranks
+ * (contiguous blocks in cell order; DRT_PARTITION=mod: the reference's round-robin deal); point sources are listed on
+ * every rank, which then runs every np_mpi-th (source, sector) task of them (rt_routines.f90:1356-1358). */
+int drt_get_sources(drt_ctx *ctx, int32_t rt_type, int32_t *cells, int32_t capacity, int32_t *count);
 int drt_reset_counters(drt_ctx *ctx);
 
 /* Introspection (no GPU needed): how an arena of `arena_bytes` is split among `waves` wavefronts carrying `lp`

@@ -208,6 +208,98 @@ def test_gpu_counters_match_oracle(name, golden, pkg):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("name,partition", [("blobB", "block"), ("blobD", "mod"), ("trusti32", "cyclic")])
+def test_two_ranks_in_one_process_match_golden(name, partition, golden, pkg, monkeypatch):
+    """The product's multi-rank path on ONE GPU: two library contexts (np_mpi = 2, id_mpi = 0 / 1) run every stage on
+    their share of the work - cell sources partitioned by build_src_list (chunks of consecutive cells dealt round the
+    ranks, one contiguous block per rank, or the reference's i = im*np_mpi + id_mpi with DRT_PARTITION=mod), the (source, sector) tasks of point sources dealt round the ranks -
+    and rt_mpi's arithmetic (io_routines.f90:3667-3855: u_final - u_fest clamp, (np-1)/np lum_lost correction, sums)
+    runs on zero-copy aliases of the contexts' device buffers with the all-reduce replaced by an in-process sum
+    (parallel.rt_mpi_local; over RCCL the same step list runs through torch.distributed). Both ranks must end with the
+    reference's single-rank result."""
+    import torch
+    from dartray_amd import parallel
+    monkeypatch.setenv("DRT_PARTITION", partition)
+    monkeypatch.setenv("DRT_PARTITION_CHUNK", "16")  # several chunks per rank on these small grids
+    z, path = golden(name)
+    case = pkg.grids.read_case(path, name)
+    ranks = [pkg.DartRayGPU(case, np_mpi=2, id_mpi=r) for r in (0, 1)]
+    one = pkg.DartRayGPU(case)
+    for g in ranks + [one]:
+        g.rt_prepare("start")
+
+    def mpi(rt):
+        torch.cuda.synchronize()
+        parallel.rt_mpi_local(pkg.host.RTT[rt], [g.mpi_fields(rt) for g in ranks])
+        torch.cuda.synchronize()
+
+    def check_partition(rt):
+        all_src = one.sources(rt)
+        parts = [g.sources(rt) for g in ranks]
+        if rt.endswith("_src"):     # point sources: every rank lists them all, the sector tasks are shared
+            assert all(list(p) == list(all_src) for p in parts), rt
+        else:                       # cell sources: a partition of the emitting leaves, balanced to one cell
+            assert sorted(np.concatenate(parts)) == sorted(all_src) and len(set(parts[0]) & set(parts[1])) == 0, rt
+            assert abs(len(parts[0]) - len(parts[1])) <= (1 if partition == "block" else 16 if partition == "cyclic" else len(all_src)), rt
+
+    for rt in ("precalc_cell", "precalc_src"):
+        check_partition(rt)
+        for g in ranks:
+            g.rt_loop(rt)
+    mpi("precalc_src")
+    for g in ranks:
+        assert relmax(g.u_fest, z["u_fest"]) <= RTOL and relelem(g.u_fest, z["u_fest"]) <= RTOL_ELEM
+        g.rt_prepare("prep_part2")
+    one.rt_loop("precalc_cell"); one.rt_loop("precalc_src"); one.rt_mpi("precalc_src"); one.rt_prepare("prep_part2")
+    for rt in ("dir_cell", "dir_src"):
+        check_partition(rt)
+        for g in ranks:
+            g.rt_loop(rt)
+    mpi("dir_src")
+    for g in ranks:
+        assert relmax(g.u_final, z["u_final_dir"]) <= RTOL and relelem(g.u_final, z["u_final_dir"]) <= RTOL_ELEM
+        assert relmax(g.lum_lost, z["lum_lost_dir"]) <= 1e-7
+        for il in range(g.L):
+            golden_scaspe_check(z, "scaspe_dir", il, g.scaspe(il), RTOL, name, RTOL_ELEM)
+    while True:
+        cn = [g.scatt_prepare() for g in ranks]
+        assert cn[0] == cn[1]
+        if cn[0]:
+            break
+        for g in ranks:
+            g.rt_loop("scatt")
+        mpi("scatt")
+    for g in ranks:
+        assert g.iterations == int(z["iterations"])
+        assert relmax(g.u_final, z["u_final"]) <= RTOL and relelem(g.u_final, z["u_final"]) <= RTOL_ELEM
+        assert relmax(g.lum_lost, z["lum_lost"]) <= 1e-7
+        for il in range(g.L):
+            golden_scaspe_check(z, "scaspe_tot", il, g.scaspe_tot(il), RTOL, name, RTOL_ELEM)
+    # observer pass: the main rank only (rt_routines.f90:1483)
+    if ranks[0].ndir:
+        for g in ranks:
+            g.rt_prepare("i_obs"); g.rt_loop_iobs("i_obs")
+        assert float(np.abs(ranks[1].i_obs).max()) == 0.0
+    for g in ranks + [one]:
+        g.close()
+
+
+def test_rt_mpi_without_communicator_is_an_error(golden, pkg):
+    """np_mpi > 1 set through drt_set_params but no communicator of that size (drt_comm_init): the fields of the rank
+    are partial sums, drt_rt_mpi must refuse (DRT_E_COMM = -6) instead of passing them on; and a communicator whose
+    size or rank contradicts np_mpi / id_mpi is refused at drt_comm_init."""
+    z, path = golden("cube65")
+    case = pkg.grids.read_case(path, "cube65")
+    g = pkg.DartRayGPU(case, np_mpi=2, id_mpi=1)
+    g.rt_prepare("start")
+    g.rt_loop("precalc_cell"); g.rt_loop("precalc_src")
+    with pytest.raises(pkg.host.DartRayError, match="-6"):
+        g.rt_mpi("precalc_src")
+    with pytest.raises(pkg.host.DartRayError, match="-2"):
+        g.comm_init(4, 1, b"\0" * 128)
+    g.close()
+
+
 def test_energy_budget_slab(pkg):
     """Known-answer check (SURVEY.md section 8c ii): with albedo 0 nothing is scattered; what the slab
     absorbs is below the source luminosity and the luminosity written off as lum_lost stays under the
