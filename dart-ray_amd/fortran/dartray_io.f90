@@ -106,6 +106,8 @@ module dartray_io_gpu
   ! ---- state the readers fill
   integer :: lnum_tot
   real(kind=real64), allocatable :: lambda_arr(:), dens_ref(:), dens_stars_ref(:)
+  real(kind=real64), allocatable :: kext_arr(:)   ! extinction coefficient per wavelength (read_av_opacities)
+  real(kind=real64) :: kext_ref                   ! ... and at lambda_ref
   integer(kind=int32), allocatable :: ncell(:)
   real(kind=real64), parameter :: cspeed = 2.99792458E8, parsec = 3.08567758E16   ! smooth_grid_routines.f90 (single-precision literals)
 contains
@@ -345,7 +347,7 @@ contains
     enddo
     close(u)
     tkext = tkabs + tksca
-    allocate(ksca_arr_norm(0:lnum-1), gsca_arr(0:lnum-1))
+    allocate(ksca_arr_norm(0:lnum-1), gsca_arr(0:lnum-1), kext_arr(0:lnum-1))
     k = 0
     do i = 0, opnum-1
        if (k > lnum-1) exit
@@ -355,10 +357,195 @@ contains
        m = (tksca(i) - tksca(i-1))/(tlambda(i)-tlambda(i-1)); c = tksca(i) - m*tlambda(i); ksca = m*lambda_arr(k)+c
        m = (tgsca(i) - tgsca(i-1))/(tlambda(i)-tlambda(i-1)); c = tgsca(i) - m*tlambda(i); gsca_arr(k) = m*lambda_arr(k)+c
        ksca_arr_norm(k) = ksca/kext
+       kext_arr(k) = kext*1E-4     ! [cm^2] -> [m^2] (:1912); only ratios to kext_ref are used
        k = k + 1
     enddo
     if (k < lnum) call stop_prc('STOP(read_av_opacities): wavelength above the tabulated range')
+    ! interpolate to lambda_ref (:1904-1908, value_locate :1662-1722)
+    if (lambda_ref <= tlambda(0)) then
+       i = 1
+    else if (lambda_ref >= tlambda(opnum-1)) then
+       i = opnum-1
+    else
+       do i = 1, opnum-1
+          if (lambda_ref > tlambda(i-1) .and. lambda_ref <= tlambda(i)) exit
+       enddo
+    endif
+    m = (tkext(i) - tkext(i-1))/(tlambda(i)-tlambda(i-1)); c = tkext(i) - m*tlambda(i)
+    kext_ref = (m*lambda_ref+c)*1E-4
   end subroutine read_av_opacities
+
+  !> scale_dens_arr (rt_routines.f90:5018-5071): without lambda grids dens_arr(lambda) is the main grid's dens (the
+  !> extinction coefficient at lambda_ref) times kext(lambda)/kext_ref; with them, the two must agree within 5E-3 in
+  !> every dusty leaf cell ("Did you use the same dust model when creating the grids ?").
+  subroutine scale_dens_arr()
+    integer :: i, j
+    real(kind=real64), allocatable :: temp_arr(:)
+    dens_ref = dens_ref/(kext_ref)
+    if (.not. use_lambda_grid) then
+       do i = 0, lnum-1
+          dens_arr(i,:) = dens_ref(:)*kext_arr(i)
+       enddo
+    else
+       allocate(temp_arr(0:tot_ncell-1))
+       do i = 0, lnum-1
+          temp_arr = dens_ref(:)*kext_arr(i)
+          do j = 0, tot_ncell-1
+             if (cchild(j) /= -1 .or. dens_ref(j) == 0) cycle
+             if (abs(temp_arr(j)-dens_arr(i,j))/temp_arr(j) > 5E-3) then
+                print *, 'STOP(scale_dens_arr): the input lambda grid dust density and that calculated by rescaling the ', &
+                     'reference grid values do not match! Did you use the same dust model when creating the grids ?'
+                print *, 'lambda = ', lambda_arr(i)
+                print *, 'cell ID = ', j
+                print *, 'lambda grid value = ', dens_arr(i,j)
+                print *, 'scaled value = ', temp_arr(j)
+                stop 1
+             endif
+          enddo
+       enddo
+       deallocate(temp_arr)
+    endif
+    dens_ref = dens_ref*kext_ref
+  end subroutine scale_dens_arr
+
+  !> check_input (io_routines.f90:2745-3303), the checks that concern this path: the algorithm, the files grid_initialize
+  !> is going to open, units, and the allowed ranges of the RT parameters (:3015-3125). All problems are listed
+  !> before stopping (error_stop).
+  subroutine check_input()
+    logical :: error, ex
+    error = .FALSE.
+    select case (trim(adjustl(rt_algorithm)))
+    case ('main')
+    case ('not_provided')
+       print *, 'ERROR: Input rt_algorithm missing'; error = .TRUE.
+    case default
+       print *, 'ERROR: rt_algorithm = ', trim(rt_algorithm), ' is outside the GPU path (stellar-emission RT: rt_algorithm = ''main'')'
+       error = .TRUE.
+    end select
+    if (dir_runs == 'not_provided') then
+       print *, 'ERROR: Input dir_runs missing'; error = .TRUE.
+    endif
+    if (grid_file == 'not_provided') then
+       print *, 'ERROR: Input grid_file missing'; error = .TRUE.
+    else
+       inquire(file=trim(adjustl(dir_grid))//trim(adjustl(grid_file)), exist=ex)
+       if (.not. ex) then
+          print *, 'ERROR: file not found: ', trim(adjustl(dir_grid))//trim(adjustl(grid_file)); error = .TRUE.
+       endif
+    endif
+    if (use_dir_out) call need_file(dir_grid, file_dir_out, 'file_dir_out', error)
+    if (use_p_src) call need_file(dir_grid, file_p_src, 'file_p_src', error)
+    if (use_lambda_grid .and. label_model_lambda_grid == 'not_provided') then
+       print *, 'ERROR: use_lambda_grid = .TRUE. needs label_model_lambda_grid'; error = .TRUE.
+    endif
+    if (label_model_out == 'not_provided') then
+       print *, 'ERROR: Input label_model_out missing'; error = .TRUE.
+    endif
+    if (.not. input_av_opacities) then
+       print *, 'ERROR: this driver needs input_av_opacities = .TRUE. and file_av_opacities (effective opacities; the grain-size ', &
+            'integration of prepare_dust_model is outside the GPU path)'
+       error = .TRUE.
+    else
+       call need_file('', file_av_opacities, 'file_av_opacities', error)
+    endif
+    if (lambda_ref <= 0) then
+       print *, 'ERROR: Invalid lambda_ref value'; print *, 'lambda_ref = ', lambda_ref; print *, 'Allowed range = (0,Inf]'
+       error = .TRUE.
+    endif
+    select case (trim(adjustl(units_luminosity)))
+    case ('erg/s/Hz', 'W/Hz')
+    case ('not_provided')
+       print *, 'ERROR: input units_luminosity missing!'; error = .TRUE.
+    case default
+       print *, 'ERROR: units_luminosity not recognized! Possible choices: erg/s/Hz, W/Hz.'; error = .TRUE.
+    end select
+    select case (trim(adjustl(units_csize)))
+    case ('pc')
+    case ('not_provided')
+       print *, 'ERROR: input units_csize missing!'; error = .TRUE.
+    case default
+       print *, 'ERROR: units_csize not recognized! Possible choices are: pc.'; error = .TRUE.
+    end select
+    if (error) call stop_prc('STOP(check_input): see the errors above')
+    ! ---- parameters (:3015-3125)
+    if (kp_sca_max < 0 .or. kp_sca_max > 4) then
+       print *, 'ERROR: Invalid kp_sca_max value'; print *, 'kp_sca_max = ', kp_sca_max; print *, 'Allowed range = [0,4]'
+       error = .TRUE.
+    endif
+    if (rad_lim < 0 .or. rad_lim > 2) then
+       print *, 'ERROR: Invalid rad_lim value'; print *, 'rad_lim =', rad_lim; print *, 'Allowed range = [0, 2]'
+       error = .TRUE.
+    endif
+    if (accuracy < 0 .or. accuracy > 1) then
+       print *, 'ERROR: Invalid accuracy value'; print *, 'accuracy = ', accuracy; print *, 'Allowed range = [0,1]'
+       error = .TRUE.
+    endif
+    if (conv_en_lim < 0. .or. conv_en_lim > 1) then
+       print *, 'ERROR: Invalid conv_en_lim value'; print *, 'conv_en_lim = ', conv_en_lim; print *, 'Allowed range = [0,1]'
+       error = .TRUE.
+    endif
+    if (bm_par < 0 .or. bm_par > 1000) then
+       print *, 'ERROR: Invalid bm_par value'; print *, 'bm_par = ', bm_par; print *, 'Allowed range = [0,1000]'
+       error = .TRUE.
+    endif
+    if (bm_par_sca < 0 .or. bm_par_sca > 1000) then
+       print *, 'ERROR: Invalid bm_par_sca value'; print *, 'bm_par_sca = ', bm_par_sca; print *, 'Allowed range = [0,1000]'
+       error = .TRUE.
+    endif
+    if (bm_par_max < 10*maxval([bm_par, bm_par_sca])) then
+       print *, 'ERROR: Invalid bm_par_max value'; print *, 'bm_par_max = ', bm_par_max
+       print *, 'Allowed range = [10*max([bm_par,bm_par_sca]), inf]'
+       error = .TRUE.
+    endif
+    if (limit_scattering_iterations) then
+       if (max_sca_iterations < 0 .or. max_sca_iterations > 10**6) then
+          print *, 'ERROR: Invalid max_sca_iterations value'; print *, 'max_sca_iterations = ', max_sca_iterations
+          print *, 'Allowed range = [0,1E6]'
+          error = .TRUE.
+       endif
+       print *, 'WARNING: limit_scattering_iteration = .TRUE. The maximum number of scattering iterations will be :', max_sca_iterations
+    endif
+    if (print_sed) then
+       if (dist_obs <= 0.1) then
+          print *, 'ERROR: Invalid dist_obs'; print *, 'dist_obs = ', dist_obs; print *, 'Allowed range = (0.1, Inf]'
+          error = .TRUE.
+       endif
+    endif
+    ! walls (:3243-3275)
+    if (x_wall_on) call check_wall(x_wall_coord, 'X', error)
+    if (y_wall_on) call check_wall(y_wall_coord, 'y', error)
+    if (z_wall_on) call check_wall(z_wall_coord, 'z', error)
+    if (error) call stop_prc('STOP(check_input): see the errors above')
+    ! ---- what the reference would go on to do and this program does not
+    if (no_communications .and. .not. sequential_scattering) sequential_scattering = .TRUE.   ! (:3187-3190)
+    if (.not. no_communications) print *, 'WARNING: the communication mode of the reference is not built; ranks hold the whole grid (no_communications)'
+    if (.not. no_dust_rt) print *, 'WARNING: no_dust_rt = .FALSE.: the dust-emission RT is outside the GPU path, the run ends after the stellar-emission RT'
+    if (print_maps) print *, 'WARNING: print_maps = .TRUE.: surface-brightness maps are outside the GPU path and will not be written'
+    if (use_pos_obs) print *, 'WARNING: use_pos_obs = .TRUE.: internal observers are outside the GPU path and are ignored'
+  contains
+    subroutine need_file(dir, name, what, err)
+      character(len=*), intent(in) :: dir, name, what
+      logical, intent(inout) :: err
+      logical :: there
+      if (name == 'not_provided') then
+         print *, 'ERROR: Input ', what, ' missing'; err = .TRUE.
+         return
+      endif
+      inquire(file=trim(adjustl(dir))//trim(adjustl(name)), exist=there)
+      if (.not. there) then
+         print *, 'ERROR: file not found: ', trim(adjustl(dir))//trim(adjustl(name)); err = .TRUE.
+      endif
+    end subroutine need_file
+    subroutine check_wall(w, ax, err)
+      real(kind=real64), intent(in) :: w(2)
+      character(len=*), intent(in) :: ax
+      logical, intent(inout) :: err
+      if (w(1) > w(2) .or. (w(1) < 0) .or. (w(2) > 1)) then
+         print *, 'ERROR: ', ax, '_wall_coord values not allowed!'; print *, ax, '_wall_coord = ', w
+         err = .TRUE.
+      endif
+    end subroutine check_wall
+  end subroutine check_input
 
   !> Point-source spectra: the reference leaves lum_p_src_arr to the model's user routine (set_trustI,
   !> user_routines_trustI.f90:253-280: log-log interpolation of a two-column table, :131-156). Here the table
@@ -367,17 +554,37 @@ contains
     real(kind=real64), allocatable :: tl(:), tlum(:,:)
     real(kind=real64) :: lam, m_t, c_t
     integer :: u, nlines, n, i, j, il, iq(1)
+    logical :: bb_there
+    real(kind=real64) :: l2
     if (tot_p_src == 0) return
-    if (file_param_src == 'not_provided') call stop_prc('ERROR: use_p_src needs file_param_src (source spectra table)')
-    open(newunit=u, file=trim(adjustl(dir_grid))//trim(adjustl(file_param_src)), status='old')
-    call count_lines(u, nlines)
-    n = nlines - 1
-    allocate(tl(0:n-1), tlum(0:tot_p_src-1, 0:n-1))
-    read(u, *)
-    do i = 0, n-1
-       read(u, *) tl(i), (tlum(j,i), j = 0, tot_p_src-1)
-    enddo
-    close(u)
+    if (file_param_src == 'not_provided') then
+       ! the TRUST-I main program (dartray_trustI.f90:27, set_trustI, user_routines_trustI.f90:250-285) takes the spectrum of
+       ! its one star from <dir_grid>BB_T10000_L100000.dat: lambda [um], L_nu [erg/s/Hz], L_lambda; read_planck_table_trustI
+       ! (:95-156) skips six header lines and interpolates log-log
+       inquire(file=trim(adjustl(dir_grid))//'BB_T10000_L100000.dat', exist=bb_there)
+       if (.not. bb_there .or. tot_p_src /= 1) call stop_prc('ERROR: use_p_src needs file_param_src (source spectra table)')
+       open(newunit=u, file=trim(adjustl(dir_grid))//'BB_T10000_L100000.dat', status='old')
+       call count_lines(u, nlines)
+       n = nlines - 7
+       allocate(tl(0:n-1), tlum(0:0, 0:n-1))
+       do i = 1, 6
+          read(u, *)
+       enddo
+       do i = 0, n-1
+          read(u, *) tl(i), tlum(0,i), l2
+       enddo
+       close(u)
+    else
+       open(newunit=u, file=trim(adjustl(dir_grid))//trim(adjustl(file_param_src)), status='old')
+       call count_lines(u, nlines)
+       n = nlines - 1
+       allocate(tl(0:n-1), tlum(0:tot_p_src-1, 0:n-1))
+       read(u, *)
+       do i = 0, n-1
+          read(u, *) tl(i), (tlum(j,i), j = 0, tot_p_src-1)
+       enddo
+       close(u)
+    endif
     do il = 0, lnum-1
        lam = lambda_arr(il)
        if (lam < tl(0)) call stop_prc('lambda smaller than tabulated lambda in table')
@@ -398,13 +605,15 @@ contains
     call read_main_grid
     if (use_lambda_grid) then
        call read_lambda_grid
-    else
-       call stop_prc('ERROR: this driver needs use_lambda_grid = .TRUE. (per-wavelength dens / dens_stars files)')
+    else if (any(dens_stars_ref /= 0)) then
+       ! without lambda grids the reference's user routines give the stellar emissivity its spectrum (e.g. set_galaxy)
+       call stop_prc('ERROR: the main grid holds stellar emissivity: its spectrum needs use_lambda_grid = .TRUE. (dens_stars per wavelength)')
     endif
     call read_dir_out
     call read_p_src
     call set_units
-    call read_av_opacities
+    call read_av_opacities      ! prepare_dust_model with input_av_opacities: kext_arr, kext_ref, albedo, g
+    call scale_dens_arr
     call read_param_src
     call set_walls
     np_mpi = 1; id_mpi = 0; main_prc = .TRUE.

@@ -150,12 +150,15 @@ def write_outputs(gpu, label: str, lambdas, out_dir: str, stage: str) -> None:
         write_array(j(filename(label, -1.0, "sed_dir" if part2 else "sed")), "sed_arr_dir" if part2 else "sed_arr", [L, ndir], gpu.sed())
 
 
-def write_reference_inputs(case, lambdas, root: str, label: str = "model") -> str:
+def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_lambda_grid: bool = True, iref: int = 0) -> str:
     """Write `case` (grids.Case) as the set of files the reference's main programs read (and
     dart-ray_amd/fortran/dartray_gpu_main reads): <root>/GRIDS/ with the HDF5 main grid, one lambda grid per
     wavelength, the wavelength list, dir_out and point-source files, an effective-opacity table in the layout
     of DUST_OPACITY/TRUST/*_Effective.dat and the source spectra table; <root>/RUNS/ for the output; and
-    <root>/input.in with the three namelists. Returns the path of input.in."""
+    <root>/input.in with the three namelists. Returns the path of input.in.
+    use_lambda_grid = False leaves the per-wavelength grids out: the run then scales the main grid's dens with
+    kext(lambda)/kext(lambda_ref) from the opacity table (scale_dens_arr, rt_routines.f90:5018), which needs a case whose
+    dens columns are multiples of each other and which has no diffuse stellar emission."""
     lambdas = [float(x) for x in lambdas]
     L = case.lnum
     assert len(lambdas) == L and all(b > a for a, b in zip(lambdas, lambdas[1:]))
@@ -163,10 +166,16 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model") -> st
     os.makedirs(gdir, exist_ok=True)
     os.makedirs(rdir, exist_ok=True)
     t = case.tree
-    iref = 0
     write_main_grid(os.path.join(gdir, f"grid_{label}.h5"), t, case.dens[:, iref], case.dens_stars[:, iref])
-    for il, lam in enumerate(lambdas):
-        write_lambda_grid(os.path.join(gdir, lambda_grid_filename(label, lam)), case.dens[:, il], case.dens_stars[:, il])
+    if use_lambda_grid:
+        for il, lam in enumerate(lambdas):
+            write_lambda_grid(os.path.join(gdir, lambda_grid_filename(label, lam)), case.dens[:, il], case.dens_stars[:, il])
+    else:
+        assert not case.dens_stars.any(), "main-grid-only runs have no way to give diffuse emission a spectrum"
+    # extinction coefficient per wavelength relative to the reference one: what scale_dens_arr multiplies dens with
+    jmax = int(np.argmax(case.dens[:, iref]))
+    kscale = case.dens[jmax, :] / case.dens[jmax, iref]
+    assert np.allclose(case.dens, case.dens[:, iref:iref + 1] * kscale[None, :], rtol=1e-12, atol=0.0)
     with open(os.path.join(gdir, "lambda_list.dat"), "w") as f:
         for lam in lambdas:
             f.write(f"{lam!r}\n")
@@ -190,9 +199,9 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model") -> st
         f.write("effective quantities written by dart-ray_amd/io.py\n   lam         Cabs          Csca        Tau\n"
                 "   [um]       [cm^2]        [cm^2]      [/N_H]           a           g\n" + "-" * 77 + "\n")
         K = 1e-21
-        rows = [(0.5 * lambdas[0], case.ksca_norm[0], case.gsca[0])] + [(lam, case.ksca_norm[il], case.gsca[il]) for il, lam in enumerate(lambdas)]
-        for lam, a, g in rows:
-            f.write(f"{lam!r} {(1.0 - float(a)) * K!r} {float(a) * K!r} {K!r} {float(a)!r} {float(g)!r}\n")
+        rows = [(0.5 * lambdas[0], case.ksca_norm[0], case.gsca[0], kscale[0])] + [(lam, case.ksca_norm[il], case.gsca[il], kscale[il]) for il, lam in enumerate(lambdas)]
+        for lam, a, g, ks in rows:
+            f.write(f"{lam!r} {(1.0 - float(a)) * K * float(ks)!r} {float(a) * K * float(ks)!r} {K * float(ks)!r} {float(a)!r} {float(g)!r}\n")
     wc = np.asarray(case.wall_coord, dtype=np.float64)
     ms = t.modelsize
     frac = [[float(v) for v in row] for row in (wc + ms / 2.0) / ms]  # set_walls maps fractions of modelsize to model coordinates
@@ -212,7 +221,7 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model") -> st
                 f"x_wall_coord = {frac[0][0]!r}, {frac[0][1]!r},\ny_wall_coord = {frac[1][0]!r}, {frac[1][1]!r},\n"
                 f"z_wall_coord = {frac[2][0]!r}, {frac[2][1]!r},\nmax_sca_iterations = {max(case.max_sca_iterations, 0)}\n/\n")
         f.write("&dartray_input_logical\n"
-                f"use_lambda_grid = .TRUE.,\nuse_dir_out = {fl(ndir > 0)},\nuse_p_src = {fl(nsrc > 0)},\nprint_output_part1 = .TRUE.,\n"
+                f"use_lambda_grid = {fl(use_lambda_grid)},\nuse_dir_out = {fl(ndir > 0)},\nuse_p_src = {fl(nsrc > 0)},\nprint_output_part1 = .TRUE.,\n"
                 "print_output_part2 = .TRUE.,\nprint_scaspe_part2 = .TRUE.,\nprint_scaspe_tot = .TRUE.,\nprint_sed = .TRUE.,\n"
                 "input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\n"
                 f"x_wall_on = {fl(case.wall_on[0])},\ny_wall_on = {fl(case.wall_on[1])},\nz_wall_on = {fl(case.wall_on[2])},\n"

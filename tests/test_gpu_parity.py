@@ -410,6 +410,43 @@ def test_fortran_main_on_reference_style_inputs(pkg, tmp_path):
     g.close()
 
 
+def test_fortran_main_scales_the_main_grid_like_scale_dens_arr(pkg, tmp_path):
+    """The shipped TRUST-I input (TRUSTI_GRIDS/input_trustI_tau0.01_LD.in) has no lambda grids: grid_initialize scales the
+    main grid's dens with kext(lambda)/kext(lambda_ref) from the effective-opacity table (scale_dens_arr,
+    rt_routines.f90:5018-5071). dartray_gpu_main on such an input set (use_lambda_grid unset, opacity table carrying the
+    extinction curve) must give the fields of the run that reads one grid per wavelength and of a direct run through the
+    C ABI; with lambda grids the 5E-3 consistency check of scale_dens_arr is exercised on the way."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "fortran", "dartray_gpu_main")
+    if not os.path.exists(exe) or not os.path.exists(pkg.io.LIB_PATH):
+        pytest.skip("Fortran main program / HDF5 library not built")
+    idx = [8, 11, 14]
+    lambdas = [float(pkg.grids.TRUSTI_TABLE[i, 0]) for i in idx]
+    case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=2, wavelengths=idx, max_sca_iterations=2)
+    g = pkg.DartRayGPU(case)
+    g.run_all(31)
+    N, nsrc, ndir = g.N, g.nsrc, g.ndir
+    for sub, lg in (("main_only", False), ("lambda_grids", True)):
+        root = str(tmp_path / sub)
+        os.makedirs(root)
+        # as in the shipped input, the reference wavelength (1 um) is not the first of the list
+        inp = pkg.io.write_reference_inputs(case, lambdas, root, label="slab", use_lambda_grid=lg, iref=1)
+        out = subprocess.run([exe, inp], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        f = lambda lam, what: os.path.join(root, "RUNS", pkg.io.filename("slab", lam, what))
+        for il, lam in enumerate(lambdas):
+            assert relmax(pkg.io.read_array(f(lam, "ufield"), "u_final", [N]), g.u_final[:, il]) <= RTOL, (sub, il)
+            assert relmax(pkg.io.read_array(f(lam, "scaspe_tot"), "scaspe_tot", [g.npix[il], N]), g.scaspe_tot(il)) <= RTOL, (sub, il)
+        assert relmax(pkg.io.read_array(f(-1.0, "sed"), "sed_arr", [g.L, ndir]), g.sed()) <= 1e-9
+    # a lambda grid that contradicts the opacity table by 1 % is refused, as in the reference
+    bad = case.dens.copy(); bad[:, 2] *= 1.01
+    pkg.io.write_lambda_grid(os.path.join(root, "GRIDS", pkg.io.lambda_grid_filename("slab", lambdas[2])), bad[:, 2], case.dens_stars[:, 2])
+    out = subprocess.run([exe, inp], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "scale_dens_arr" in out.stdout
+    g.close()
+
+
 @pytest.mark.parametrize("name", ["magtar_shell", "galaxy"])
 def test_full_size_configs_energy_budget(name, pkg):
     """BASELINE configs 3 and 4 at their full sizes (128 009 and 33 211 cells), where the oracle is too slow to be
