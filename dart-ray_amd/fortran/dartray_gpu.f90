@@ -173,8 +173,11 @@ module dartray_c
   end interface
 end module dartray_c
 
+#ifndef DRT_REAL_MODULES
 !> Stand-in for the module state of smooth_grid_routines.f90 / rt_routines.f90: same names, kinds,
 !> ranks and lower bounds (0-based as allocated by read_main_grid, io_routines.f90:329-332).
+!> Built with -DDRT_REAL_MODULES (make linktest, build container only) the facade uses the REFERENCE's modules instead:
+!> that build proves that every name, kind and rank the facade relies on exists there as declared here.
 module dartray_state
   use iso_fortran_env
   implicit none
@@ -203,13 +206,27 @@ module dartray_state
        rtt_prep_part2 = 4, rtt_dir_cell = 5, rtt_i_obs_dir_cell = 6, rtt_dir_src = 7, rtt_i_obs_dir_src = 8, &
        rtt_output_part2 = 9, rtt_scatt = 10, rtt_i_obs = 11
 end module dartray_state
+#endif
 
 !> The facade: dartray_hub.f90's driver procedures on top of the GPU library.
 module dartray_hub_gpu
   use iso_c_binding
   use iso_fortran_env
   use dartray_c
+#ifdef DRT_REAL_MODULES
+  ! inside the reference: the module state itself (rt_routines re-exports smooth_grid_routines); only the data is
+  ! imported - rt_routines' own rt_loop / rt_loop_iobs are the procedures this facade replaces
+  use rt_routines, only: var_arr_2d, tot_ncell, max_lvl, tot_p_src, tot_ndir, tot_ndir_scaspe, base, lnum, cchild, lvl, src_cell, &
+       cindex, ccoord, csize, dens_arr, dens_stars_arr, u_fest_arr, u_final_arr, lumcell, lum_p_src_arr, ccoord_p_src, &
+       dir_i_out, ksca_arr_norm, gsca_arr, lum_lost, i_obs_arr, sed_arr, sed_arr_dir, scaspe_arr, scaspe_tot_arr, &
+       npix_arr, npix_hp_arr, kp_sca_arr, kp_sca_max, bm_par, bm_par_sca, bm_par_max, rad_lim, en_lim, conv_en_lim, &
+       accuracy, cs, dist_obs, modelsize, x_wall_on, y_wall_on, z_wall_on, cnflag, done, limit_scattering_iterations, &
+       x_wall_coord, y_wall_coord, z_wall_coord, rt_type, iterations, max_sca_iterations, np_mpi, id_mpi, main_prc, &
+       rtt_start, rtt_precalc_cell, rtt_precalc_src, rtt_output_part1, rtt_prep_part2, rtt_dir_cell, rtt_i_obs_dir_cell, &
+       rtt_dir_src, rtt_i_obs_dir_src, rtt_output_part2, rtt_scatt, rtt_i_obs
+#else
   use dartray_state
+#endif
   implicit none
   type(c_ptr), save :: gpu_ctx = c_null_ptr
   integer :: gpu_device = 0

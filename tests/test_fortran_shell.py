@@ -98,3 +98,22 @@ def test_main_grid_only_needs_emission_free_main_grid(pkg, tmp_path):
     open(inp, "w").write(txt.replace("use_lambda_grid = .TRUE.", "use_lambda_grid = .FALSE."))
     r = subprocess.run([exe, inp, "0", "test_run"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "stellar emissivity" in r.stdout
+
+
+def test_facade_links_against_the_reference_modules(pkg):
+    """INTEGRATION.md tells a maintainer to replace `use dartray_state` by the reference's modules. `make linktest` does
+    exactly that (-DDRT_REAL_MODULES: `use rt_routines, only: <every name the facade touches>`), compiles the facade
+    against the .mod files of the UNMODIFIED reference modules (oracle/_ref/build) and links it with their objects: a
+    kind, rank or name mismatch (bm_par, scaspe_arr%a, the rtt_* ids ...) or a clash with rt_routines' own rt_loop would
+    fail here. Build container only."""
+    import shutil
+    if not os.path.isdir(REF) or shutil.which("amdflang") is None:
+        pytest.skip("needs /root/reference and amdflang (build container)")
+    fdir = os.path.join(os.path.dirname(pkg.__file__), "fortran")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "build", "rt_routines.mod")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    shutil.rmtree(os.path.join(fdir, "_linktest"), ignore_errors=True)
+    r = subprocess.run(["make", "-C", fdir, "linktest"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = subprocess.run([os.path.join(fdir, "_linktest", "linktest")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "facade linked against the reference modules" in out.stdout
