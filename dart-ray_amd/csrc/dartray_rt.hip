@@ -79,6 +79,7 @@ struct drt_ctx {
     bool ray_major = false;
     bool big_tables = false;  // some wavelength's slot table has more than 63 slots (set_npix_arr)
     int G_cell = 0;  // sectors per task that last fitted the queue arena for cell sources (0: not tried yet)
+    int G_want[16] = {0};  // per rt_type: sectors per task suggested by the work per source of the last call of that stage
     std::vector<double*> d_bak_scaspe;  // snapshot of the accumulators of a stage, restored when a launch is repeated
     double *d_bak_u = nullptr, *d_bak_lost = nullptr;
     unsigned long long* d_bak_cnt = nullptr;  // lane = ray kernel (rt_wide.hpp) instead of lane = (ray, wavelength)
@@ -858,6 +859,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     int rc;
     std::vector<int> list;
     if ((rc = build_src_list(c, rt_type, list))) return rc;
+    const int64_t inter_before = c->cnt.intersections;  // the device counters run on until drt_reset_counters
     c->cnt.sources = (int64_t)list.size();
     c->cnt.kernel_ms = 0; c->cnt.launches = 0;
     if (list.empty()) return DRT_OK;
@@ -981,7 +983,14 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     } else {
         // Cell sources: G sectors per task. More sectors fill the lanes better (and merge more rays per atomic) but
         // lengthen the queues; how long they get depends on the grid. The value that fitted is kept for the next call.
-        int Gtry = c->G_cell > 0 ? std::min(c->G_cell, 16) : G;
+        // Sectors per task. 16 fill a wave's 64 lanes with first-level rays and merge most rays per atomic: best when a
+        // source launches many rays (TRUST-I tau = 1: ~8e4 intersections per source). When a source is cheap (tau = 0.01:
+        // ~9e2) a task is a handful of steps, mostly waiting for memory, and four times as many smaller tasks keep more
+        // waves busy (12.8 -> 8.6 ms). The choice follows the intersections per source of the previous call of the same
+        // stage (a run repeats its scattering stage); first call: 8.
+        int Gtry = c->G_want[rt_type & 15] > 0 ? c->G_want[rt_type & 15] : 8;
+        if (c->G_cell > 0) Gtry = std::min(Gtry, c->G_cell);
+        Gtry = std::min(Gtry, G);
         if (const char* e = getenv("DRT_SECTORS_PER_TASK")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = std::min(Gtry, v); }
         int max_blocks = c->waves / 4;
         for (;;) {
@@ -1005,7 +1014,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             else if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;  // then fewer waves with deeper ones
             else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
-        c->G_cell = Gtry;
+        if (c->cnt.launches > 1) c->G_cell = Gtry;  // an overflow was met: more sectors than this do not fit this arena
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, 0));
@@ -1014,7 +1023,12 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->cnt.kernel_ms = ms;
     if ((rc = check_device_error(c))) return rc;
-    return pull_counters(c);
+    if ((rc = pull_counters(c))) return rc;
+    if (!psrc && c->cnt.sources > 0) {
+        const double ips = (double)(c->cnt.intersections - inter_before) / (double)c->cnt.sources;
+        c->G_want[rt_type & 15] = ips < 4000.0 ? 4 : ips < 20000.0 ? 8 : 16;
+    }
+    return DRT_OK;
 }
 
 extern "C" int drt_rt_loop_iobs(drt_ctx* c, int32_t rt_type)

@@ -90,10 +90,17 @@ __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 6
 __device__ __forceinline__ double bcast_d(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int first_lane_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // Orders the global-memory traffic of the lanes of ONE wave: stores of some lanes (queue appends, parked rays, hash
-// slots) are read by other lanes after it. A full fence at agent scope (wait for the stores, write back, invalidate
-// the vector L1): a few microseconds, issued a few times per task. A workgroup-scope fence (waits only) also passed
-// every test, but it relies on this CU's L1 never holding an older copy of a line another lane has just rewritten.
-__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
+// slots) are read by other lanes after it. A fence at WORKGROUP scope: s_waitcnt vmcnt(0) and nothing else. That is what
+// the AMDGPU memory model prescribes for a release/acquire pair inside one work-group (gfx90a/gfx942 family, work-groups
+// not split across CUs): the waves of a work-group share their CU's write-through vector L1, a store updates it on its
+// way to L2, so a later load of the same CU cannot see an older copy - and the lanes of one wave are the narrowest case
+// of that. The agent-scope fence used before (buffer_wbl2 + buffer_inv: write back and invalidate the XCD's L2 and the
+// L1) costs microseconds each, tens of them per task, and the L2 write-backs of 3 000 waves queue behind one another:
+// with it a task carried ~0.3 ms of fixed cost (TRUST-I tau = 0.01: 72 ms at one sector per task against 15 ms at 16).
+#ifndef DRT_FENCE_SCOPE
+#define DRT_FENCE_SCOPE "workgroup"
+#endif
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, DRT_FENCE_SCOPE); }
 // OR over the wave. The result steers wave-uniform control flow, so it is handed back through readfirstlane: a value
 // the compiler can prove uniform lives in a scalar register (a uniform value kept in a vector register can be spilled
 // inside divergent code, where only the active lanes are saved).

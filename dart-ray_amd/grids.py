@@ -577,7 +577,18 @@ def galaxy_case(max_lvl: int = 3, base=(3, 3), nlambda: int = 3, modelsize: floa
 
     tree = build_tree(modelsize, base, max_lvl, refine, balance=True)
     N = tree.ncell
-    lam_scale = np.array([1.6, 1.0, 0.55, 0.3, 0.18, 0.1][:nlambda])
+    if nlambda <= 6:
+        lam_scale = np.array([1.6, 1.0, 0.55, 0.3, 0.18, 0.1][:nlambda])
+        star_spec = np.array([0.4, 1.0, 1.3, 1.1, 0.8, 0.5][:nlambda])
+        alb = np.array([0.62, 0.58, 0.5, 0.4, 0.3, 0.2][:nlambda])
+        gg = np.array([0.55, 0.5, 0.42, 0.3, 0.2, 0.1][:nlambda])
+    else:
+        # many wavelengths (BASELINE config 4 names 24; the shipped list has 16 below 5 um): the TRUST dust columns from
+        # 0.15 um on, extinction relative to the 0.53-um entry, a 10^4-K stellar spectrum shape
+        tab = TRUSTI_TABLE[2:2 + nlambda]
+        lam_scale = tab[:, 1] / TRUSTI_TABLE[8, 1]
+        star_spec = tab[:, 4] / tab[:, 4].max()
+        alb, gg = tab[:, 2].copy(), tab[:, 3].copy()
     L = lam_scale.shape[0]
     kd = kdust(tree.ccoord)
     kd[kd < 1e-4 * kdust0] = 0.0
@@ -586,14 +597,14 @@ def galaxy_case(max_lvl: int = 3, base=(3, 3), nlambda: int = 3, modelsize: floa
     R = np.sqrt(c[:, 0] ** 2 + c[:, 1] ** 2)
     stars = np.exp(-R / hr - np.abs(c[:, 2]) / hz_stars) + 4.0 * np.exp(-(c ** 2).sum(axis=1) / (2 * bulge_r ** 2))
     stars[stars < 2e-3] = 0.0
-    dens_stars = (stars * tree.leaf)[:, None] * np.array([0.4, 1.0, 1.3, 1.1, 0.8, 0.5][:L])[None, :] * 1e20
+    dens_stars = (stars * tree.leaf)[:, None] * star_spec[None, :] * 1e20
     wall_coord = np.zeros((3, 2))
     wall_on = (False, False, False)
     if walls:
         wall_on = (False, False, True)
         wall_coord[2] = np.array([0.3, 0.7]) * modelsize - modelsize / 2.0
-    return Case(tree=tree, dens=dens, dens_stars=dens_stars, ksca_norm=np.array([0.62, 0.58, 0.5, 0.4, 0.3, 0.2][:L]),
-                gsca=np.array([0.55, 0.5, 0.42, 0.3, 0.2, 0.1][:L]), p_src_pos=np.zeros((0, 3)), p_src_lum=np.zeros((0, L)),
+    return Case(tree=tree, dens=dens, dens_stars=dens_stars, ksca_norm=alb,
+                gsca=gg, p_src_pos=np.zeros((0, 3)), p_src_lum=np.zeros((0, L)),
                 dir_out=_observer_dirs(ndir), kp_sca_max=1, rad_lim=0.1017, accuracy=0.3, conv_en_lim=0.01, bm_par=5,
                 bm_par_sca=5, bm_par_max=200, wall_on=wall_on, wall_coord=wall_coord, dist_obs=10e6, name=name, **kw)
 
@@ -656,9 +667,16 @@ def nbody_case(max_lvl: int = 3, base=(3, 3), nlambda: int = 2, modelsize: float
     # normalise: optical depth ~1 through the densest cell at the first wavelength
     kmax = gas.max() if gas.max() > 0 else 1.0
     smallest = float(tree.csize.min())
-    dens = (gas / kmax * (1.0 / smallest))[:, None] * np.array([1.0, 0.45, 0.2, 0.1][:L])[None, :]
-    dens_stars = stars[:, None] * np.array([1.0, 1.4, 1.1, 0.7][:L])[None, :]
-    return Case(tree=tree, dens=dens, dens_stars=dens_stars, ksca_norm=np.array([0.6, 0.5, 0.4, 0.3][:L]),
-                gsca=np.array([0.5, 0.35, 0.2, 0.0][:L]), p_src_pos=np.zeros((0, 3)), p_src_lum=np.zeros((0, L)),
+    if L <= 4:
+        kscale, sspec = np.array([1.0, 0.45, 0.2, 0.1][:L]), np.array([1.0, 1.4, 1.1, 0.7][:L])
+        alb, gg = np.array([0.6, 0.5, 0.4, 0.3][:L]), np.array([0.5, 0.35, 0.2, 0.0][:L])
+    else:  # many wavelengths (BASELINE config 5 names 28): TRUST dust columns from 0.15 um on, relative to 0.53 um
+        tab = TRUSTI_TABLE[2:2 + L]
+        kscale, sspec = tab[:, 1] / TRUSTI_TABLE[8, 1], tab[:, 4] / tab[:, 4].max()
+        alb, gg = tab[:, 2].copy(), tab[:, 3].copy()
+    dens = (gas / kmax * (1.0 / smallest))[:, None] * kscale[None, :]
+    dens_stars = stars[:, None] * sspec[None, :]
+    return Case(tree=tree, dens=dens, dens_stars=dens_stars, ksca_norm=alb,
+                gsca=gg, p_src_pos=np.zeros((0, 3)), p_src_lum=np.zeros((0, L)),
                 dir_out=_observer_dirs(ndir), kp_sca_max=1, rad_lim=0.1023, accuracy=0.3, conv_en_lim=0.01, bm_par=5,
                 bm_par_sca=5, bm_par_max=200, dist_obs=10e3, name=name, **kw)

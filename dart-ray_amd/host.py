@@ -96,8 +96,9 @@ def lib():
         L.drt_comm_unique_id.argtypes = [C.c_char_p]
         L.drt_comm_init.argtypes = [vp, i32, i32, C.c_char_p]
         L.drt_comm_destroy.argtypes = [vp]
-        L.drt_get_sources.argtypes = [vp, i32, ip, i32, ip]
-        L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        if hasattr(L, "drt_get_sources"):  # absent from libraries of older revisions (A/B runs through DRT_LIB)
+            L.drt_get_sources.argtypes = [vp, i32, ip, i32, ip]
+            L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 

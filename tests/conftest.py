@@ -29,6 +29,20 @@ def load_pkg():
     return mod
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_sees_the_gpu_first():
+    """On a GPU box: let torch initialise its HIP state before the library creates contexts and arenas (torch's lazy
+    initialisation, reached late from a test that aliases device buffers, failed with "No HIP GPUs are available" when
+    a dozen library contexts had come and gone before it). Nothing happens without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return load_pkg()

@@ -29,7 +29,7 @@ def stage(name, fn):
         tot = max(raw[15], 1)
         names = ["setup", "step", "flush", "park", "next", "commit", "extract"]
         print("    phases % of wave time:", {n: round(100 * raw[8 + i] / tot, 1) for i, n in enumerate(names)},
-              "steps", raw[16], "busy lanes/step", round(raw[17] / max(raw[16], 1), 1),
+              "steps", raw[16], "cycles/step", int(tot / max(raw[16], 1)), "sum of wave times / (100 MHz ticks -> ms)", round(tot / 1e5, 1), "busy lanes/step", round(raw[17] / max(raw[16], 1), 1),
               "rays/group", round(raw[19] / max(raw[18], 1), 2))
         print("    wavelength loop % of wave time:", {n: round(100 * raw[22 + i] / tot, 1) for i, n in enumerate(["deposit", "group head", "members", "epilogue"])},
               "lambda iterations/step", round(raw[26] / max(raw[16], 1), 1), "groups/step", round(raw[18] / max(raw[16], 1), 1),
