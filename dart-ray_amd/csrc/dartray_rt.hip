@@ -115,6 +115,8 @@ struct drt_ctx {
     double* d_ring_tab[14] = {nullptr}, *d_phi0_tab[14] = {nullptr}, *d_phi1_tab[14] = {nullptr};
     double* d_dir_out_sc = nullptr;
     int tab_max_level = 0;
+    double* d_hgnorm[14] = {nullptr};
+    int hgnorm_max = 0;
     drt_counters cnt{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // comm (RCCL, loaded lazily)
@@ -207,6 +209,7 @@ extern "C" int drt_destroy(drt_ctx* c)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
     if (c->d_dir_out_sc) (void)hipFree(c->d_dir_out_sc);
+    for (int k = 0; k < 14; k++) if (c->d_hgnorm[k]) (void)hipFree(c->d_hgnorm[k]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     drt_comm_destroy(c);
@@ -462,6 +465,8 @@ static int upload_problem(drt_ctx* c)
     P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap; P.dbg_flags = c->dbg_flags;
     for (int k = 0; k < 14; k++) { P.ring_tab[k] = c->d_ring_tab[k]; P.phi0_tab[k] = c->d_phi0_tab[k]; P.phi1_tab[k] = c->d_phi1_tab[k]; }
     P.tab_max_level = c->tab_max_level;
+    for (int k = 0; k < 14; k++) P.hgnorm[k] = c->d_hgnorm[k];
+    P.hgnorm_max = c->hgnorm_max;
     P.dir_out_sc = c->d_dir_out_sc;
     HIPCHK(c, hipMemcpy(c->d_prob, &P, sizeof P, hipMemcpyHostToDevice));
     return DRT_OK;
@@ -679,6 +684,25 @@ static int prepare_part2(drt_ctx* c)
     }
     if ((rc = dev_zero(c, &c->d_i_obs, (size_t)(c->ndir > 0 ? c->ndir : 1) * (N + c->nsrc) * L))) return rc;
     c->part2 = true;
+    // HG normalisation per ray direction (DevProblem::hgnorm): levels nside 4 .. 256 by default (268 MB at 32 wavelengths;
+    // DRT_HGNORM_NSIDE changes the finest tabulated nside, 0 switches the table off)
+    for (int k = 0; k < 14; k++) if (c->d_hgnorm[k]) { (void)hipFree(c->d_hgnorm[k]); c->d_hgnorm[k] = nullptr; }
+    c->hgnorm_max = 0;
+    if ((rc = upload_problem(c))) return rc;
+    int kmax = 8;
+    if (const char* e = getenv("DRT_HGNORM_NSIDE")) { const int n = atoi(e); kmax = 0; while (kmax < 11 && (1 << (kmax + 1)) <= n) kmax++; if (n < 4) kmax = 0; }
+    kmax = std::min(kmax, c->tab_max_level);
+    bool any_hg = false;
+    for (int il = 0; il < L; il++) if (c->ik[il] >= 0) any_hg = true;
+    if (any_hg && kmax >= 2) {
+        for (int k = 2; k <= kmax; k++) {
+            const long long n = (12ll << (2 * k)) * L;
+            HIPCHK(c, hipMalloc((void**)&c->d_hgnorm[k], (size_t)n * sizeof(double)));
+            hipLaunchKernelGGL(k_hgnorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, c->d_prob, k, c->d_hgnorm[k]);
+        }
+        HIPCHK(c, hipDeviceSynchronize());
+        c->hgnorm_max = kmax;
+    }
     return upload_problem(c);
 }
 

@@ -74,6 +74,12 @@ struct DevProblem {
     const double* phi0_tab[14];
     const double* phi1_tab[14];
     int tab_max_level;         // largest k with tables; finer levels fall back to device sin/cos/acos
+    // HG normalisation of calc_ffn_arr (rt_routines.f90:2252-2260), sum over the HEALPix slots of x**-1.5, tabulated per
+    // ray direction: hgnorm[k] = [12*4^k pixels][L] for nside = 2^k <= 2^hgnorm_max (1.0 for isotropic wavelengths). A
+    // ray direction is a pixel centre, the sum depends on nothing else: one load per (ray, wavelength) deposit
+    // replaces 48 (or 12) x**-1.5 per wavelength of every launched ray. Finer rays compute it at launch as before.
+    const double* hgnorm[14];
+    int hgnorm_max;
     const double* dir_out_sc;  // [ndir][4] sin(theta), cos(theta), sin(phi), cos(phi) of the observer directions
     // optional debug trace of ray launches: dbg[0] = count, then records of 6 ints
     int* dbg;

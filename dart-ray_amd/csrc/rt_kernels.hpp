@@ -617,7 +617,10 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                                 }
                                 r.nx = nx; r.ny = ny; r.nz = nz;
                                 const double* tab = lam_ok ? P.tab[il] : nullptr;
-                                if (r.lam_active && tab) {
+                                if (r.lam_active && tab && nsl <= P.hgnorm_max) {
+                                    // tabulated per direction (DevProblem::hgnorm); "reco" rays use pixel 1 like their direction
+                                    r.tot_hg = P.hgnorm[nsl][(unsigned long long)((is_reco && level <= 256) ? 1 : ipix_dir) * P.L + il];
+                                } else if (r.lam_active && tab) {
                                     const double g = P.g[il];
                                     const int np = P.npix[il], hp = P.npix_hp[il];
                                     const double ga = 1.0 + g * g, gb = 2.0 * g;
@@ -1129,6 +1132,37 @@ __global__ void __launch_bounds__(256, DRT_WAVES_FOR(LP)) rt_stage_kernel(const 
 __global__ void __launch_bounds__(256, 3) rt_stage_kernel_1w3(const DevProblem* __restrict__ Pp, StageArgs a)
 {
     rt_stage_body<1>(Pp, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// HG normalisation table of one HEALPix level (DevProblem::hgnorm): one thread per (pixel, wavelength), the arithmetic
+// of the launch-time evaluation (trace_items, trace_items_w) to the letter.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double hg_norm(const DevProblem& P, int l, double nx, double ny, double nz)
+{
+    const double* tab = P.tab[l];
+    if (!tab) return 1.0;
+    const double g = P.g[l];
+    const int np = P.npix[l], hp = P.npix_hp[l];
+    const double ga = 1.0 + g * g, gb = 2.0 * g;
+    double tot = 0;
+    for (int p = 0; p < hp; p++) {
+        const double ads = tab[p] * nx + tab[np + p] * ny + tab[2 * np + p] * nz;
+        tot += pow_m1p5(ga - gb * ads);
+    }
+    return tot;
+}
+
+__global__ void k_hgnorm(const DevProblem* __restrict__ Pp, int k, double* __restrict__ out)
+{
+    const DevProblem& P = *Pp;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long npixk = 12ll << (2 * k);
+    if (idx >= npixk * P.L) return;
+    const int pix = (int)(idx / P.L), l = (int)(idx % P.L);
+    PixDir pd;
+    pix2ang_nest_sc(P, 1 << k, pix, pd);
+    out[idx] = hg_norm(P, l, pd.st * pd.cp, pd.st * pd.sp, pd.ct);
 }
 
 // ------------------------------------------------------------------------------------------------

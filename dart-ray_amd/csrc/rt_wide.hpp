@@ -263,6 +263,8 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
     const int nsl = 31 - __clz(level);
     bool busy = false;
     int my_item = 0;
+    int hgpix = 0;                 // row of the HG-normalisation table this ray reads (its pixel; 1 for "reco" rays)
+    const double* const hgtab = (nsl <= P.hgnorm_max) ? P.hgnorm[nsl] : nullptr;  // wave-uniform: all rays of this call share nside
     unsigned long long amask = 0;  // the ray's iq list (sticky, set_iq_list :1860-1893)
     Ray r;
     r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
@@ -342,6 +344,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                 nx = p1.st * p1.cp; ny = p1.st * p1.sp; nz = p1.ct;
                             }
                             r.nx = nx; r.ny = ny; r.nz = nz;
+                            hgpix = (is_reco && level <= 256) ? 1 : ipix_dir;
                             bst[2 * DRT_BST + lane] = nx; bst[3 * DRT_BST + lane] = ny; bst[4 * DRT_BST + lane] = nz;  // read by every lane in flush_lambda
                             busy = true;
                             fresh = true;
@@ -367,8 +370,9 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                             if (I > 0) amask |= 1ull << l;
                         }
                     }
-                    if (a.scatter) {
-                        // calc_ffn_arr (rt_routines.f90:2186-2281): sum over the HEALPix slots of x**-1.5. The slot
+                    if (a.scatter && !hgtab) {
+                        // calc_ffn_arr (rt_routines.f90:2186-2281): sum over the HEALPix slots of x**-1.5 - only for rays
+                        // finer than the tabulated levels (DevProblem::hgnorm), the others read it when they deposit. The slot
                         // cosines do not depend on the wavelength: wavelengths that share a slot table go through the
                         // slots together, HGB at a time (one dot product per slot instead of one per slot and wavelength).
                         constexpr int HGB = 8;
@@ -488,8 +492,9 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 // operands of wavelength l for this lane: dens_arr(l, cc) and, in ONE more load whose meaning follows the
                 // branch, u_fest_arr(l, cc) (br 1) or the ray's HG normalisation (br 2)
                 const double* const p_dens = H.dens + (unsigned long long)cc_s * L;
-                const double* const p_aux = (br == 1) ? H.u_fest_r + (unsigned long long)cc_s * L : (br == 2) ? thg + lane : p_dens;
-                const int aux_stride = (br == 2) ? 64 : 1;
+                const double* const p_aux = (br == 1) ? H.u_fest_r + (unsigned long long)cc_s * L
+                                            : (br == 2) ? (hgtab ? hgtab + (unsigned long long)hgpix * L : thg + lane) : p_dens;
+                const int aux_stride = (br == 2 && !hgtab) ? 64 : 1;
                 double dn = 0.0, ax = 1.0;
                 if (br != 0 && (amask & 1ull)) { dn = gload(p_dens); ax = gload(p_aux); }
 #pragma nounroll
