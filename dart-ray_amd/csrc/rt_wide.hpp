@@ -162,19 +162,23 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
     const unsigned long long srow0 = readlane_u64(LT.srow, l);
     const double ga = 1.0 + g * g, gb = 2.0 * g;
     const double tx = (reg == 1) ? T.x1 : T.x0, ty = (reg == 1) ? T.y1 : T.y0, tz = (reg == 1) ? T.z1 : T.z0;
-    unsigned na = 0, nl = 0;  // atomic instructions and their active lanes (wave-uniform, scalar registers)
+    const bool slot_lane = lane < np;   // lanes that are scaspe slots of this wavelength (all of them below np <= 63)
+    unsigned na = 0, nl = 0;            // atomic instructions and their active lanes (wave-uniform, scalar registers)
+    // u_final: the sum of a cell group is handed to the group's first lane; ONE atomic instruction after the loop adds
+    // the sums of all groups (each lane to its own cell). The row atomics then have a scalar base and the lane as offset.
+    double su_lead = 0.0;
+    unsigned long long leaders = 0ull;
     while (M) {
         TSTAMP(tg0);
         const int src = __ffsll((long long)M) - 1;
         const int cc_b = __builtin_amdgcn_readlane(cc, src);
         const unsigned long long grp = __ballot(cc == cc_b) & Mall;
         M &= ~grp;
+        leaders |= 1ull << src;
 #ifdef DRT_PROFILE
         wc.n_groups++; wc.n_memb += __popcll(grp);
         if (reg < 0) wc.n_cls2 += __popcll(grp); else if (reg == 0) wc.n_cls0 += __popcll(grp); else wc.n_cls1 += __popcll(grp);
 #endif
-        const unsigned long long row = srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)np);
-        const unsigned long long urow = (unsigned long long)H.u_final + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)H.L + (unsigned)l);
         double su = 0.0;
         unsigned long long gc = grp & MC;   // members with scattered energy
         unsigned long long gu = grp & ~MC;  // members that only add to u_final
@@ -186,38 +190,40 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
         TSTAMP(tg1);
         TACC(t_ghead, tg0, tg1);
         if (!BIG || reg < 2) {
-            double acc = 0.0;
-            if (reg < 0) {  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
-                while (gc) {
-                    const int m = __ffsll((long long)gc) - 1;
-                    gc &= gc - 1;
-                    acc += bst[m];
-                    su += bst[DRT_BST + m];
+            if (grp & MC) {
+                double acc = 0.0;
+                if (reg < 0) {  // isotropic: ffn = 1/npix_hp with npix_hp = 1 (:2266)
+                    while (gc) {
+                        const int m = __ffsll((long long)gc) - 1;
+                        gc &= gc - 1;
+                        acc += bst[m];
+                        su += bst[DRT_BST + m];
+                    }
+                } else {
+                    while (gc) {
+                        const int m = __ffsll((long long)gc) - 1;
+                        gc &= gc - 1;
+                        const double Cm = bst[m];
+                        su += bst[DRT_BST + m];
+                        const double nx = bst[2 * DRT_BST + m], ny = bst[3 * DRT_BST + m], nz = bst[4 * DRT_BST + m];
+                        const double cs = __builtin_fma(tz, nz, __builtin_fma(ty, ny, tx * nx));
+                        acc = __builtin_fma(Cm, pow_m1p5_f(__builtin_fma(-gb, cs, ga)), acc);
+                    }
                 }
-            } else {
-                while (gc) {
-                    const int m = __ffsll((long long)gc) - 1;
-                    gc &= gc - 1;
-                    const double Cm = bst[m];
-                    su += bst[DRT_BST + m];
-                    const double nx = bst[2 * DRT_BST + m], ny = bst[3 * DRT_BST + m], nz = bst[4 * DRT_BST + m];
-                    const double cs = __builtin_fma(tz, nz, __builtin_fma(ty, ny, tx * nx));
-                    acc = __builtin_fma(Cm, pow_m1p5_f(__builtin_fma(-gb, cs, ga)), acc);
-                }
+                TSTAMP(tg2);
+                TACC(t_memb, tg1, tg2);
+                double* const rowp = (double*)(srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)np));  // wave-uniform
+                const bool go = slot_lane && acc != 0.0;
+                const unsigned long long gb_ = __ballot(go);
+                na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
+                if (go) DRT_ATOMIC(H, rowp + lane, acc);
+                TSTAMP(tg3);
+                TACC(t_epi, tg2, tg3);
             }
-            TSTAMP(tg2);
-            TACC(t_memb, tg1, tg2);
-            double* const addr = (double*)((lane == 63) ? urow : row + 8ull * (unsigned)lane);
-            const double v = (lane == 63) ? su : acc;
-            const bool go = (lane < np || lane == 63) && v != 0.0;
-            const unsigned long long gb_ = __ballot(go);
-            na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
-            if (go) DRT_ATOMIC(H, addr, v);
-            TSTAMP(tg3);
-            TACC(t_epi, tg2, tg3);
         } else {
             // slot table with more slots than lanes: 64 slots at a time from memory, the rays of the group summed per slot
             const double* tab = P.tab[l];
+            double* const rowp = (double*)(srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)np));
             for (int p0 = 0; p0 < np; p0 += 64) {
                 const int p = p0 + lane;
                 double px = 0, py = 0, pz = 0;
@@ -236,12 +242,16 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
                 const bool go = (p < np) && a2 != 0.0;
                 const unsigned long long gb_ = __ballot(go);
                 na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
-                if (go) DRT_ATOMIC(H, (double*)(row + 8ull * (unsigned)p), a2);
+                if (go) DRT_ATOMIC(H, rowp + p, a2);
             }
-            const bool gu1 = (lane == 63) && su != 0.0;
-            if (__ballot(gu1)) { na++; nl++; }
-            if (gu1) DRT_ATOMIC(H, (double*)urow, su);
         }
+        su_lead = (lane == src) ? su : su_lead;
+    }
+    {
+        const bool go = ((leaders >> lane) & 1ull) && su_lead != 0.0;
+        const unsigned long long gb_ = __ballot(go);
+        na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
+        if (go) DRT_ATOMIC(H, H.u_final + ((unsigned long long)(unsigned)cc * (unsigned)H.L + (unsigned)l), su_lead);
     }
     wc.atom += na; wc.atom_lanes += nl;
 }
