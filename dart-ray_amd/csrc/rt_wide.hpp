@@ -22,7 +22,10 @@
                            // set-up passes; measured 32: 1801 ms, 48: 1758, 64: 1738 (TRUST-I, 32 wavelengths, 21 801 cells)
 #endif
 #ifndef DRT_WIDE_WAVES
-#define DRT_WIDE_WAVES 2  // waves per SIMD the register allocator provisions for rt_stage_wide
+#define DRT_WIDE_WAVES 3  // waves per SIMD the register allocator provisions for rt_stage_wide (168 registers; with the ray
+                          // intensities in the arena LDS no longer caps the CU at 8 waves). Measured on the bench workload
+                          // after the deposit loop had been rolled up: 2 waves + intensities in LDS 6.98 s per step, 2 waves +
+                          // arena 7.2 s, 3 waves + arena 6.65 s, 4 waves + arena 7.98 s (128 registers: spills in the loop)
 #endif
 struct SlotTabs { double x0, y0, z0, x1, y1, z1; };  // unit vectors of scaspe slot `lane` of slot tables 0 and 1 (where they fit the lanes)
 
@@ -39,8 +42,12 @@ struct SlotTabs { double x0, y0, z0, x1, y1, z1; };  // unit vectors of scaspe s
 // compiler cannot infer the space (e.g. at -O1), and a FLAT f64 atomic on an LDS address raises
 // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.
 typedef __attribute__((address_space(3))) double ldouble;
-// Ray intensities [L][64] of the wave: LDS by default; -DDRT_I_GLOBAL keeps them in the wave's arena slice instead (after the
-// HG normalisations), which frees 16 KB of LDS per wave at 32 wavelengths, i.e. lifts the LDS limit on resident waves.
+// Ray intensities [L][64] of the wave live in the wave's arena slice (after the HG normalisations): in LDS they take 16 KB
+// per wave at 32 wavelengths and cap the CU at 8 waves. -DDRT_I_LDS puts them back into LDS (needs DRT_WIDE_WAVES <= 2
+// at 32 wavelengths).
+#ifndef DRT_I_LDS
+#define DRT_I_GLOBAL
+#endif
 #ifdef DRT_I_GLOBAL
 typedef double* iptr_t;
 #define DRT_I_WORDS(L) 0
