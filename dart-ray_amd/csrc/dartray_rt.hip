@@ -25,12 +25,12 @@
 // calc_total_luminosity_sca (rt_routines.f90:698-708): lumcell(il,i) = sum(scaspe(0:npix_hp-1,i)) for leaves;
 // totals per wavelength for the convergence test (:725-732) and tot_rad_en (:675-684)
 __global__ void k_lumcell_sca(const double* __restrict__ scaspe, const int* __restrict__ cchild, double* __restrict__ lumcell,
-                              double* __restrict__ tot, int N, int L, int il, int npix, int nhp, int all_pix)
+                              double* __restrict__ tot, int N, int L, int il, int npix, int nhp, int all_pix, int nstride)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     double s = 0.0;
     if (i < N) {
-        const double* row = scaspe + (unsigned long long)i * npix;
+        const double* row = scaspe + (unsigned long long)i * nstride;
         int n = all_pix ? npix : nhp;
         for (int p = 0; p < n; p++) s += row[p];
         lumcell[(unsigned long long)i * L + il] = (cchild[i] == -1) ? s : 0.0;
@@ -85,6 +85,7 @@ struct drt_ctx {
     unsigned long long* d_bak_cnt = nullptr;  // lane = ray kernel (rt_wide.hpp) instead of lane = (ray, wavelength)
     std::vector<double> ksca, gsca;
     std::vector<int> npix, npix_hp, kp, ik;
+    std::vector<int> nstride;  // device row length of the scaspe arrays (npix rounded up to 8 doubles = one 64-byte line)
     int nuniq = 0;
     std::vector<int> kp_unique, npix_unique;
     int nsrc = 0, ndir = 0;
@@ -351,6 +352,9 @@ static void set_npix_arr(drt_ctx* c)
         c->npix_hp[i] = 12 * (1 << (2 * k_min));
     }
     for (int i = 0; i < L; i++) c->npix[i] = c->npix_hp[i] + c->ndir;  // tot_ndir_scaspe = tot_ndir (io_routines.f90:559)
+    c->nstride.assign(L, 0);
+    const char* ra = getenv("DRT_ROW_ALIGN");  // developer aid: 0 keeps the rows dense (A/B of the padded layout)
+    for (int i = 0; i < L; i++) c->nstride[i] = (ra && ra[0] == '0') ? c->npix[i] : (c->npix[i] + 7) / 8 * 8;
     c->big_tables = false;
     for (int i = 0; i < L; i++) if (c->kp[i] >= 0 && c->npix[i] > 63) c->big_tables = true;
     c->nuniq = 0; c->kp_unique.clear(); c->npix_unique.clear();
@@ -449,7 +453,7 @@ static int upload_problem(drt_ctx* c)
     P.lum_lost = c->d_lum_lost; P.i_obs = c->d_i_obs;
     for (int il = 0; il < c->L; il++) {
         P.ksca[il] = c->ksca[il]; P.g[il] = c->gsca[il];
-        P.npix[il] = c->npix[il]; P.npix_hp[il] = c->npix_hp[il]; P.kp[il] = c->kp[il];
+        P.npix[il] = c->npix[il]; P.npix_hp[il] = c->npix_hp[il]; P.kp[il] = c->kp[il]; P.nstride[il] = c->nstride[il];
         P.scaspe[il] = il < (int)c->d_scaspe.size() ? c->d_scaspe[il] : nullptr;
         P.scaspe_prev[il] = il < (int)c->d_scaspe_prev.size() ? c->d_scaspe_prev[il] : nullptr;
         P.scaspe_tot[il] = il < (int)c->d_scaspe_tot.size() ? c->d_scaspe_tot[il] : nullptr;
@@ -666,7 +670,7 @@ static int prepare_part2(drt_ctx* c)
     free_fields(c);
     c->d_scaspe.assign(L, nullptr); c->d_scaspe_prev.assign(L, nullptr); c->d_scaspe_tot.assign(L, nullptr);
     int rc;
-    for (int il = 0; il < L; il++) if ((rc = dev_zero(c, &c->d_scaspe[il], (size_t)N * c->npix[il]))) return rc;
+    for (int il = 0; il < L; il++) if ((rc = dev_zero(c, &c->d_scaspe[il], (size_t)N * c->nstride[il]))) return rc;
     c->d_tab.assign(c->nuniq, nullptr);
     for (int u = 0; u < c->nuniq; u++) {
         int n = c->npix_unique[u], nhp = n - c->ndir, nside_sca = 1 << c->kp_unique[u];
@@ -712,7 +716,7 @@ static int lumcell_from(drt_ctx* c, const std::vector<double*>& arr, int all_pix
     HIPCHK(c, hipMemset(c->d_tot, 0, DRT_MAXL * sizeof(double)));
     for (int il = 0; il < L; il++)
         hipLaunchKernelGGL(k_lumcell_sca, dim3((N + 255) / 256), dim3(256), 0, 0, arr[il], c->d_cchild, c->d_lumcell, c->d_tot + il, N, L, il,
-                           c->npix[il], c->npix_hp[il], all_pix);
+                           c->npix[il], c->npix_hp[il], all_pix, c->nstride[il]);
     totals.assign(L, 0.0);
     HIPCHK(c, hipMemcpy(totals.data(), c->d_tot, L * sizeof(double), hipMemcpyDeviceToHost));
     c->lumcell_h.resize((size_t)N * L);
@@ -732,7 +736,7 @@ static int prepare_scatt(drt_ctx* c)
     int rc;
     if (c->iterations == 1) {
         for (int il = 0; il < L; il++) {
-            size_t n = (size_t)N * c->npix[il];
+            size_t n = (size_t)N * c->nstride[il];
             if ((rc = dev_zero(c, &c->d_scaspe_tot[il], n))) return rc;
             HIPCHK(c, hipMemcpy(c->d_scaspe_tot[il], c->d_scaspe[il], n * sizeof(double), hipMemcpyDeviceToDevice));  // create_scaspe_tot
             if ((rc = dev_zero(c, &c->d_scaspe_prev[il], n))) return rc;                                             // create_scaspe_prev
@@ -740,7 +744,7 @@ static int prepare_scatt(drt_ctx* c)
         c->bm_par_cur = c->par.bm_par_sca;
     }
     for (int il = 0; il < L; il++)
-        HIPCHK(c, hipMemcpy(c->d_scaspe_prev[il], c->d_scaspe[il], (size_t)N * c->npix[il] * sizeof(double), hipMemcpyDeviceToDevice));
+        HIPCHK(c, hipMemcpy(c->d_scaspe_prev[il], c->d_scaspe[il], (size_t)N * c->nstride[il] * sizeof(double), hipMemcpyDeviceToDevice));
     std::vector<double> tot;
     if ((rc = lumcell_from(c, c->d_scaspe, 0, tot))) return rc;
     if (c->iterations == 1) c->tot_rad_en = tot;  // parents hold zeros, so the leaf sum equals sum over all cells (:682)
@@ -754,7 +758,7 @@ static int prepare_scatt(drt_ctx* c)
     if (c->par.max_sca_iterations >= 0 && c->iterations > c->par.max_sca_iterations) c->cnflag = 1;
     // sequential scattering bookkeeping (:747-756)
     for (int il = 0; il < L; il++) {
-        size_t n = (size_t)N * c->npix[il];
+        size_t n = (size_t)N * c->nstride[il];
         if (c->iterations > 1) hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, 0, c->d_scaspe_tot[il], c->d_scaspe[il], (unsigned long long)n);
         HIPCHK(c, hipMemsetAsync(c->d_scaspe[il], 0, n * sizeof(double), 0));
     }
@@ -937,7 +941,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if (direct && c->d_bak_scaspe.size() != (size_t)c->L) {
         for (auto p : c->d_bak_scaspe) if (p) (void)hipFree(p);
         c->d_bak_scaspe.assign(c->L, nullptr);
-        for (int il = 0; il < c->L; il++) HIPCHK(c, hipMalloc((void**)&c->d_bak_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
+        for (int il = 0; il < c->L; il++) HIPCHK(c, hipMalloc((void**)&c->d_bak_scaspe[il], (size_t)c->N * c->nstride[il] * sizeof(double)));
     }
     double* acc_u = precalc ? c->d_u_fest : c->d_u_final;
     auto copy_state = [&](bool save) -> int {
@@ -946,7 +950,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         HIPCHK(c, cp(c->d_bak_cnt, c->d_counters, CNT_N * sizeof(unsigned long long)));
         if (direct) {
             HIPCHK(c, cp(c->d_bak_lost, c->d_lum_lost, (size_t)c->L * sizeof(double)));
-            for (int il = 0; il < c->L; il++) HIPCHK(c, cp(c->d_bak_scaspe[il], c->d_scaspe[il], (size_t)c->N * c->npix[il] * sizeof(double)));
+            for (int il = 0; il < c->L; il++) HIPCHK(c, cp(c->d_bak_scaspe[il], c->d_scaspe[il], (size_t)c->N * c->nstride[il] * sizeof(double)));
         }
         return DRT_OK;
     };
@@ -1175,7 +1179,7 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
         if ((rc = allreduce_sum(c, c->d_u_final, NL))) return rc;
         if (rt_type == DRT_RTT_SCATT) hipLaunchKernelGGL(k_axpy, dim3(1024), dim3(256), 0, 0, c->d_u_final, c->d_u_fest, (unsigned long long)NL);
         // reduce_scaspe_arr (:3806-3834), one wavelength at a time
-        for (int il = 0; il < c->L; il++) if ((rc = allreduce_sum(c, c->d_scaspe[il], (size_t)c->N * c->npix[il]))) return rc;
+        for (int il = 0; il < c->L; il++) if ((rc = allreduce_sum(c, c->d_scaspe[il], (size_t)c->N * c->nstride[il]))) return rc;
         // reduce_lum_lost (:3837-3855)
         if (rt_type == DRT_RTT_SCATT && c->par.np_mpi > 1)
             hipLaunchKernelGGL(k_scale_sub, dim3(1), dim3(64), 0, 0, c->d_lum_lost, c->d_lum_lost_prev, (c->par.np_mpi - 1.0) / c->par.np_mpi, c->L);
@@ -1186,10 +1190,13 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
 }
 
 // ---- module state out ---------------------------------------------------------------------------------
-static int field_ptr(drt_ctx* c, int which, int il, double** d, size_t* n)
+// Device pointer of a field. Host arrays hold `n` elements; the scaspe arrays are kept with padded rows on the device
+// (`rows` rows of `cols` values, `stride` apart: DevProblem::nstride), every other field is dense (rows = 0).
+static int field_ptr(drt_ctx* c, int which, int il, double** d, size_t* n, size_t* rows = nullptr, size_t* cols = nullptr, size_t* stride = nullptr)
 {
     const size_t NL = (size_t)c->N * c->L;
     *d = nullptr; *n = 0;
+    if (rows) *rows = 0;
     switch (which) {
     case DRT_A_U_FEST: *d = c->d_u_fest; *n = NL; break;
     case DRT_A_U_FINAL: *d = c->d_u_final; *n = NL; break;
@@ -1203,6 +1210,7 @@ static int field_ptr(drt_ctx* c, int which, int il, double** d, size_t* n)
         auto& v = which == DRT_A_SCASPE ? c->d_scaspe : which == DRT_A_SCASPE_TOT ? c->d_scaspe_tot : c->d_scaspe_prev;
         if ((int)v.size() > il) *d = v[il];
         *n = (size_t)c->N * (c->npix.empty() ? 0 : c->npix[il]);
+        if (rows && !c->npix.empty()) { *rows = (size_t)c->N; *cols = (size_t)c->npix[il]; *stride = (size_t)c->nstride[il]; }
         break;
     }
     default: return fail(c, DRT_E_ARG, "unknown field %d", which);
@@ -1225,10 +1233,11 @@ extern "C" int drt_get_array(drt_ctx* c, int32_t which, int32_t il, double* host
         memcpy(host, c->dens_stars_h.data(), count * sizeof(double));
         return DRT_OK;
     }
-    double* d; size_t n; int rc;
-    if ((rc = field_ptr(c, which, il, &d, &n))) return rc;
+    double* d; size_t n, rows, cols, stride; int rc;
+    if ((rc = field_ptr(c, which, il, &d, &n, &rows, &cols, &stride))) return rc;
     if (n != count) return fail(c, DRT_E_ARG, "field %d holds %zu elements, caller passed %zu", which, n, count);
-    HIPCHK(c, hipMemcpy(host, d, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (rows) HIPCHK(c, hipMemcpy2D(host, cols * sizeof(double), d, stride * sizeof(double), cols * sizeof(double), rows, hipMemcpyDeviceToHost));
+    else HIPCHK(c, hipMemcpy(host, d, n * sizeof(double), hipMemcpyDeviceToHost));
     return DRT_OK;
 }
 
@@ -1249,10 +1258,11 @@ extern "C" int drt_set_array(drt_ctx* c, int32_t which, int32_t il, const double
         c->prepared = false;
         return DRT_OK;
     }
-    double* d; size_t n; int rc;
-    if ((rc = field_ptr(c, which, il, &d, &n))) return rc;
+    double* d; size_t n, rows, cols, stride; int rc;
+    if ((rc = field_ptr(c, which, il, &d, &n, &rows, &cols, &stride))) return rc;
     if (n != count) return fail(c, DRT_E_ARG, "field %d holds %zu elements, caller passed %zu", which, n, count);
-    HIPCHK(c, hipMemcpy(d, host, n * sizeof(double), hipMemcpyHostToDevice));
+    if (rows) HIPCHK(c, hipMemcpy2D(d, stride * sizeof(double), host, cols * sizeof(double), cols * sizeof(double), rows, hipMemcpyHostToDevice));
+    else HIPCHK(c, hipMemcpy(d, host, n * sizeof(double), hipMemcpyHostToDevice));
     if (which == DRT_A_LUMCELL) c->lumcell_h.assign(host, host + n);
     return DRT_OK;
 }
@@ -1260,9 +1270,9 @@ extern "C" int drt_set_array(drt_ctx* c, int32_t which, int32_t il, const double
 extern "C" int drt_device_ptr(drt_ctx* c, int32_t which, int32_t il, void** dev_ptr, size_t* count)
 {
     if (!c || !dev_ptr || !count) return DRT_E_ARG;
-    double* d; size_t n; int rc;
-    if ((rc = field_ptr(c, which, il, &d, &n))) return rc;
-    *dev_ptr = d; *count = n;
+    double* d; size_t n, rows, cols, stride; int rc;
+    if ((rc = field_ptr(c, which, il, &d, &n, &rows, &cols, &stride))) return rc;
+    *dev_ptr = d; *count = rows ? rows * stride : n;  // scaspe arrays: the padded device array (the padding stays zero)
     return DRT_OK;
 }
 

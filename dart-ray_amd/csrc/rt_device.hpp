@@ -53,7 +53,9 @@ struct DevProblem {
     // per wavelength
     double ksca[DRT_MAXL], g[DRT_MAXL];
     int npix[DRT_MAXL], npix_hp[DRT_MAXL], kp[DRT_MAXL];
-    double* scaspe[DRT_MAXL];             // [N][npix]
+    int nstride[DRT_MAXL];                // row length of the scaspe arrays: npix rounded up to 8 doubles, so that a row starts on
+                                          // a 64-byte line and an atomic instruction over it is 7 memory-side requests (55 slots), not 8
+    double* scaspe[DRT_MAXL];             // [N][nstride]
     const double* scaspe_prev[DRT_MAXL];
     const double* scaspe_tot[DRT_MAXL];
     const double* tab[DRT_MAXL];          // [3][npix]: unit vectors of the scaspe slots (x, y, z); null if isotropic

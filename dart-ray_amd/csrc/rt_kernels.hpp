@@ -376,7 +376,7 @@ struct RegTabs {
     double x0, y0, z0, x1, y1, z1;  // slot unit vectors of the first two slot tables, slot = lane
     // per-wavelength constants of THIS lane's wavelength (lane % LP); a deposit round fetches them from
     // the depositing lane with readlane instead of loading DevProblem arrays (no memory in the round)
-    int np, tid;
+    int np, ns, tid;   // slots, row stride, slot table
     double ga, gb, ksca;
     double* srow;
     // read once per kernel: after an atomic the compiler must assume *Pp changed and would load these again
@@ -419,7 +419,7 @@ __device__ __forceinline__ void flush_deposits(const DevProblem& P, const Ray& r
         pend &= ~grp;
         const int np = __builtin_amdgcn_readlane(T.np, src);
         const unsigned long long sbase = readlane_u64((unsigned long long)T.srow, src);
-        double* srow = (double*)sbase + (unsigned long long)cc_b * np;
+        double* srow = (double*)sbase + (unsigned long long)cc_b * __builtin_amdgcn_readlane(T.ns, src);
         double* uaddr = T.u_final + (unsigned long long)cc_b * T.L + il_b;
         const int tid = __builtin_amdgcn_readlane(T.tid, src);
         const double ga = readlane_d(T.ga, src), gb = readlane_d(T.gb, src);
@@ -569,7 +569,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                             // assign_src_lum (rt_routines.f90:3043-3071)
                             int kp = P.kp[il];
                             int ip = (kp >= 0) ? ang2pix_nest_z(P, 1 << kp, pd.ct, phi) : 0;
-                            src_lum = P.scaspe_prev[il][(unsigned long long)S.nc * P.npix[il] + ip] * P.npix_hp[il];
+                            src_lum = P.scaspe_prev[il][(unsigned long long)S.nc * P.nstride[il] + ip] * P.npix_hp[il];
                         }
                         const double sin_dl = pd.st, cos_dl = pd.ct, sin_al = pd.sp, cos_al = pd.cp;
                         const double d0 = sin_dl * cos_al, d1 = sin_dl * sin_al, d2 = cos_dl;  // calc_cproj :1945
@@ -970,10 +970,10 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
     int err = 0;
     TSTAMP(tk0);
     // slot unit vectors of the first two scaspe slot tables, one slot per lane
-    RegTabs T = {0, 0, 0, 0, 0, 0, 0, -1, 1.0, 0.0, 0.0, nullptr, P.u_final, P.L};
+    RegTabs T = {0, 0, 0, 0, 0, 0, 0, 0, -1, 1.0, 0.0, 0.0, nullptr, P.u_final, P.L};
     if (a.scatter && il < P.L) {
         const double g = P.g[il];
-        T.np = P.npix[il]; T.tid = P.tabid[il]; T.ga = 1.0 + g * g; T.gb = 2.0 * g; T.ksca = P.ksca[il]; T.srow = P.scaspe[il];
+        T.np = P.npix[il]; T.ns = P.nstride[il]; T.tid = P.tabid[il]; T.ga = 1.0 + g * g; T.gb = 2.0 * g; T.ksca = P.ksca[il]; T.srow = P.scaspe[il];
     }
     if (a.scatter) {
         if (P.utab[0] && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }
@@ -1203,7 +1203,7 @@ __global__ void __launch_bounds__(256) rt_iobs_kernel(const DevProblem* __restri
         if (lam_ok) {
             if (rt == RTT_I_OBS_DIR_SRC) src_lum = P.p_src_lum[(unsigned long long)P.src_cell[nc] * P.L + il];
             else if (rt == RTT_I_OBS_DIR_CELL) src_lum = P.lumcell[(unsigned long long)nc * P.L + il];
-            else src_lum = P.scaspe_tot[il][(unsigned long long)nc * P.npix[il] + P.npix_hp[il] + j] * P.npix_hp[il];
+            else src_lum = P.scaspe_tot[il][(unsigned long long)nc * P.nstride[il] + P.npix_hp[il] + j] * P.npix_hp[il];
         }
         const double* sc = P.dir_out_sc + 4ull * j;
         const double sin_dl = sc[0], cos_dl = sc[1], sin_al = sc[2], cos_al = sc[3];

@@ -21,6 +21,9 @@
                            // batch in phase (siblings cross the same cells in the same step -> more rays per atomic) and cost fewer
                            // set-up passes; measured 32: 1801 ms, 48: 1758, 64: 1738 (TRUST-I, 32 wavelengths, 21 801 cells)
 #endif
+#ifndef DRT_PHASE_K10
+#define DRT_PHASE_K10 20  // phase-alignment window of the ray-major kernel in tenths of a cell size (0 = off), see trace_items_w
+#endif
 #ifndef DRT_WIDE_WAVES
 #define DRT_WIDE_WAVES 3  // waves per SIMD the register allocator provisions for rt_stage_wide (168 registers; with the ray
                           // intensities in the arena LDS no longer caps the CU at 8 waves). Measured on the bench workload
@@ -71,7 +74,7 @@ struct HotP {
 #endif
 struct LaneTab {  // lane l: constants of wavelength l
     double g, ksca;
-    int np, tid;
+    int np, ns, tid;          // slots, row stride (np rounded up to 8), slot table
     unsigned long long srow;  // scaspe[l]
 };
 
@@ -164,6 +167,7 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
     // wave-uniform constants of the wavelength (scalar registers)
     const double g = readlane_d(LT.g, l);
     const int np = __builtin_amdgcn_readlane(LT.np, l);
+    const int ns = __builtin_amdgcn_readlane(LT.ns, l);
     const int tid = __builtin_amdgcn_readlane(LT.tid, l);
     const int reg = (tid < 0) ? -1 : (tid <= 1 && np <= 63) ? tid : 2;  // 0 / 1: register table, -1: isotropic, 2: memory table
     const unsigned long long srow0 = readlane_u64(LT.srow, l);
@@ -219,7 +223,7 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
                 }
                 TSTAMP(tg2);
                 TACC(t_memb, tg1, tg2);
-                double* const rowp = (double*)(srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)np));  // wave-uniform
+                double* const rowp = (double*)(srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)ns));  // wave-uniform, 64-byte aligned
                 const bool go = slot_lane && acc != 0.0;
                 const unsigned long long gb_ = __ballot(go);
                 na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
@@ -230,7 +234,7 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
         } else {
             // slot table with more slots than lanes: 64 slots at a time from memory, the rays of the group summed per slot
             const double* tab = P.tab[l];
-            double* const rowp = (double*)(srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)np));
+            double* const rowp = (double*)(srow0 + 8ull * ((unsigned long long)(unsigned)cc_b * (unsigned)ns));
             for (int p0 = 0; p0 < np; p0 += 64) {
                 const int p = p0 + lane;
                 double px = 0, py = 0, pz = 0;
@@ -380,7 +384,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                 // assign_src_lum (rt_routines.f90:3043-3071)
                                 const int kp = P.kp[l];
                                 if (kp != kp_prev) { ip = (kp >= 0) ? ang2pix_nest_z(P, 1 << kp, ct, phi) : 0; kp_prev = kp; }
-                                src_lum = P.scaspe_prev[l][(unsigned long long)S.nc * P.npix[l] + ip] * P.npix_hp[l];
+                                src_lum = P.scaspe_prev[l][(unsigned long long)S.nc * P.nstride[l] + ip] * P.npix_hp[l];
                             }
                             const double I = src_lum / S.norm;
                             Ilds[l * 64 + lane] = I;
@@ -461,13 +465,15 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
             // the source, but after different numbers of steps (different start cells, cell sizes, obliquity). Only
             // the lanes within DRT_PHASE_K cell sizes of the wave's smallest entry distance take this step; the
             // others wait in place, so that the rays of a cell deposit in the same step and leave the wave in one
-            // atomic. Pure scheduling: what a ray does does not depend on when it does it.
+            // atomic. Pure scheduling: what a ray does does not depend on when it does it. Pays once the kernel is bound by
+            // the memory-side atomic unit (bench: 1.99e10 64-byte requests/s = 1.27 TB/s): window 0 -> 6.62 s per step,
+            // 1 cell size -> 6.14, 2 -> 5.99, 3 -> 6.39, 4 -> 6.52 (fewer atomics against more, emptier steps).
             bool go = busy;
-#if defined(DRT_PHASE_K)
+#if DRT_PHASE_K10 > 0
             if (a.scatter) {
                 double pm = busy ? r.prev : 1.0e300;
                 for (int off = 1; off < 64; off <<= 1) pm = fmin(pm, __shfl_xor(pm, off, 64));
-                go = busy && (r.prev <= pm + (DRT_PHASE_K) * P.csize_arr[r.clvl]);
+                go = busy && (r.prev <= pm + (0.1 * DRT_PHASE_K10) * P.csize_arr[r.clvl]);
             }
 #endif
             if (go) {
@@ -673,8 +679,8 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
 #ifdef DRT_DEBUG_FLAGS
     H.skip_atomics = P.dbg_flags & 1;
 #endif
-    LaneTab LT = {0.0, 0.0, 0, -1, 0ull};
-    if (lane < P.L) { LT.g = P.g[lane]; LT.ksca = P.ksca[lane]; LT.np = P.npix[lane]; LT.tid = P.tabid[lane]; LT.srow = (unsigned long long)P.scaspe[lane]; }
+    LaneTab LT = {0.0, 0.0, 0, 0, -1, 0ull};
+    if (lane < P.L) { LT.g = P.g[lane]; LT.ksca = P.ksca[lane]; LT.np = P.npix[lane]; LT.ns = P.nstride[lane]; LT.tid = P.tabid[lane]; LT.srow = (unsigned long long)P.scaspe[lane]; }
     SlotTabs T = {0, 0, 0, 0, 0, 0};
     if (a.scatter) {
         if (P.utab[0] && P.utab_np[0] <= 63 && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }

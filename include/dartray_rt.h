@@ -136,7 +136,10 @@ int drt_rt_mpi(drt_ctx *ctx, int32_t rt_type);
 int drt_get_array(drt_ctx *ctx, int32_t which, int32_t il, double *host, size_t count);
 int drt_set_array(drt_ctx *ctx, int32_t which, int32_t il, const double *host, size_t count);
 /* Device address and element count of a field, for hosts that run the stage-end reductions
- * themselves (e.g. torch.distributed / RCCL on the same buffers). The memory stays owned by ctx. */
+ * themselves (e.g. torch.distributed / RCCL on the same buffers). The memory stays owned by ctx.
+ * The scaspe arrays are held with padded rows on the device (row length = npix rounded up to a multiple of 8, so that
+ * every cell's row starts on a 64-byte line); count is that padded size and the padding is zero, so element-wise sums
+ * over ranks are unaffected. drt_get_array / drt_set_array exchange the dense (npix, tot_ncell) arrays of the reference. */
 int drt_device_ptr(drt_ctx *ctx, int32_t which, int32_t il, void **dev_ptr, size_t *count);
 /* npix_arr, npix_hp_arr, kp_sca_arr of wavelength il (set_npix_arr, rt_routines.f90:5235) */
 int drt_get_npix(const drt_ctx *ctx, int32_t il, int32_t *npix, int32_t *npix_hp, int32_t *kp);
