@@ -518,12 +518,20 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 const double* const p_aux = (br == 1) ? H.u_fest_r + (unsigned long long)cc_s * L
                                             : (br == 2) ? (hgtab ? hgtab + (unsigned long long)hgpix * L : thg + lane) : p_dens;
                 const int aux_stride = (br == 2 && !hgtab) ? 64 : 1;
+                // the wavelengths some ray of this step still carries (wave-uniform): only those are visited
+                unsigned lo = (br != 0) ? (unsigned)amask : 0u, hi = (br != 0) ? (unsigned)(amask >> 32) : 0u;
+                for (int off = 1; off < 64; off <<= 1) lo |= (unsigned)__shfl_xor((int)lo, off, 64);
+                if (LP > 32) for (int off = 1; off < 64; off <<= 1) hi |= (unsigned)__shfl_xor((int)hi, off, 64);
+                unsigned long long lam_any = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)lo)
+                                             | ((LP > 32) ? ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) : 0ull);
+                int l = lam_any ? __ffsll((long long)lam_any) - 1 : 0;
                 double dn = 0.0, ax = 1.0;
-                if (br != 0 && (amask & 1ull)) { dn = gload(p_dens); ax = gload(p_aux); }
-#pragma nounroll
-                for (int l = 0; l < L; l++) {
+                if (br != 0 && ((amask >> l) & 1ull)) { dn = gload(p_dens + l); ax = gload(p_aux + l * aux_stride); }
+                while (lam_any) {
+                    lam_any &= lam_any - 1;
+                    const int l1 = lam_any ? __ffsll((long long)lam_any) - 1 : l;  // the next wavelength to visit
                     double dn1 = 0.0, ax1 = 1.0;
-                    if (l + 1 < L && br != 0 && ((amask >> (l + 1)) & 1ull)) { dn1 = gload(p_dens + (l + 1)); ax1 = gload(p_aux + (l + 1) * aux_stride); }
+                    if (lam_any && br != 0 && ((amask >> l1) & 1ull)) { dn1 = gload(p_dens + l1); ax1 = gload(p_aux + l1 * aux_stride); }
                     const bool act = br != 0 && ((amask >> l) & 1ull);
                     if (__ballot(act)) {
                         TSTAMP(td0);
@@ -562,7 +570,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                             }
                         }
                     }
-                    dn = dn1; ax = ax1;
+                    dn = dn1; ax = ax1; l = l1;
                 }
             }
             if (br == 1) {
