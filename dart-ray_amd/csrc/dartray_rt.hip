@@ -96,6 +96,7 @@ struct drt_ctx {
     // device
     int *d_cchild = nullptr, *d_lvl = nullptr, *d_src_cell = nullptr, *d_src_list = nullptr;
     uint32_t* d_cpack = nullptr;
+    uint32_t* d_nbr = nullptr;
     double *d_ccoord = nullptr, *d_csize = nullptr, *d_dens = nullptr, *d_u_fest = nullptr, *d_u_final = nullptr, *d_lumcell = nullptr;
     double *d_p_src_pos = nullptr, *d_p_src_lum = nullptr, *d_dir_out = nullptr, *d_lum_lost = nullptr, *d_lum_lost_prev = nullptr;
     double *d_i_obs = nullptr, *d_tot = nullptr;
@@ -203,7 +204,7 @@ extern "C" int drt_destroy(drt_ctx* c)
     if (!c) return DRT_E_ARG;
     (void)hipSetDevice(c->device);
     free_fields(c);
-    void* ptrs[] = {c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
+    void* ptrs[] = {c->d_nbr, c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
                     c->d_u_final, c->d_lumcell, c->d_p_src_pos, c->d_p_src_lum, c->d_dir_out, c->d_lum_lost, c->d_lum_lost_prev,
                     c->d_i_obs, c->d_tot, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter,
                     c->d_bak_lost, c->d_bak_cnt};
@@ -279,6 +280,42 @@ extern "C" int drt_set_grid(drt_ctx* c, int32_t N, int32_t max_lvl, const int32_
     if ((rc = dev_upload(c, &c->d_ccoord, ccoord, 3ull * N))) return rc;
     if ((rc = dev_upload(c, &c->d_csize, csize, (size_t)N))) return rc;
     if ((rc = dev_upload(c, &c->d_cpack, c->cpack.data(), 3ull * N))) return rc;
+    // Face-neighbour table (DevProblem::nbr): for every leaf and face, carry the +-1 up the levels as increment does
+    // (smooth_grid_routines.f90:751-769), walk from the root like ccindd_to_cc (:820-852) but no deeper than the leaf's level
+    if (N > 0x07FFFFFF) return fail(c, DRT_E_ARG, "drt_set_grid: more than 2^27 cells");
+    {
+        std::vector<uint32_t> nbr(6ull * N, 0xFFFFFFFFu);
+        for (int n = 1; n < N; n++) {
+            if (cchild[n] != -1) continue;
+            const int Lc = lvl[n];
+            for (int f = 0; f < 6; f++) {
+                const int ax = f >> 1, inc = (f & 1) ? 1 : -1;
+                uint32_t w[3] = {c->cpack[3ull * n], c->cpack[3ull * n + 1], c->cpack[3ull * n + 2]};
+                int k = inc;
+                for (int j = Lc; j >= 1 && k != 0; j--) {
+                    const int b = base[(j > 1) ? 1 : 0];
+                    int v = (int)((w[ax] >> (4 * (j - 1))) & 15u) + k;
+                    int ovr = k;
+                    if (v >= b) v = 0; else if (v < 0) v = b - 1; else ovr = 0;
+                    w[ax] = (w[ax] & ~(15u << (4 * (j - 1)))) | ((uint32_t)v << (4 * (j - 1)));
+                    k = ovr;
+                }
+                if (k != 0) continue;  // out of the model
+                int l = 1, found = -1, flv = 0;
+                for (int i = 1; i <= Lc; i++) {
+                    const int b = base[(i > 1) ? 1 : 0];
+                    const int kk = ((int)((w[2] >> (4 * (i - 1))) & 15u) * b + (int)((w[1] >> (4 * (i - 1))) & 15u)) * b + (int)((w[0] >> (4 * (i - 1))) & 15u);
+                    l += kk;
+                    if (l < 1 || l >= N) break;
+                    if (cchild[l] == -1 || i == Lc) { found = l; flv = i; break; }
+                    l = cchild[l];
+                }
+                if (found < 0) return fail(c, DRT_E_ARG, "drt_set_grid: no face neighbour of cell %d on face %d (broken tree)", n, f);
+                nbr[6ull * n + f] = (uint32_t)found | ((uint32_t)flv << 27) | (cchild[found] != -1 ? 0x80000000u : 0u);
+            }
+        }
+        if ((rc = dev_upload(c, &c->d_nbr, nbr.data(), nbr.size()))) return rc;
+    }
     c->have_grid = true; c->prepared = false; c->part2 = false;
     return DRT_OK;
 }
@@ -447,7 +484,7 @@ static int upload_problem(drt_ctx* c)
     P.halfpi = (double)asinf(1.0f); P.pi = 2 * P.halfpi; P.twopi = 2 * P.pi; P.twothird = (double)(2.0f / 3.0f);
     P.glepsilon = (double)1.0e-7f; P.tau_thin = (double)1.0e-8f; P.len_eps = (double)1.0e-5f;
     P.outcube_f = (double)(1.0f + 1.0e-7f); P.merge_tol = (double)0.001f;
-    P.cchild = c->d_cchild; P.lvl = c->d_lvl; P.ccoord = c->d_ccoord; P.csize = c->d_csize; P.cpack = c->d_cpack;
+    P.cchild = c->d_cchild; P.lvl = c->d_lvl; P.ccoord = c->d_ccoord; P.csize = c->d_csize; P.cpack = c->d_cpack; P.nbr = c->d_nbr;
     P.dens = c->d_dens; P.u_fest = c->d_u_fest; P.u_final = c->d_u_final; P.lumcell = c->d_lumcell;
     P.p_src_pos = c->d_p_src_pos; P.p_src_lum = c->d_p_src_lum; P.src_cell = c->d_src_cell; P.dir_out = c->d_dir_out;
     P.lum_lost = c->d_lum_lost; P.i_obs = c->d_i_obs;

@@ -39,6 +39,12 @@ struct DevProblem {
     const double* ccoord;    // [N][3]
     const double* csize;     // [N]
     const uint32_t* cpack;   // [N][3]  tree coordinates, 4 bits per level (from cindex)
+    // Face neighbours of every leaf: nbr[6*cc + 2*axis + (direction > 0)] = the cell the reference's step
+    // (rt_routines.f90:1778-1841: carry the +-1 up the levels, then ccindd_to_cc from the root) ends in when it does not
+    // have to descend below the level of cc: bits 0-26 cell, bits 27-30 its level, bit 31 set when that cell is
+    // subdivided (the ray then descends with the coordinates of the finer levels); 0xFFFFFFFF: the ray leaves the model.
+    // One load instead of a walk of lvl(cc) dependent loads from the root.
+    const uint32_t* nbr;
     // fields, wavelength fastest: [N][L]
     const double* dens;
     double* u_fest;

@@ -268,6 +268,47 @@ __device__ __forceinline__ bool step_axis(const DevProblem& P, uint32_t& w, int 
     return true;
 }
 
+// The step into the next cell (rt_routines.f90:1778-1851) through the face-neighbour table. Same cell as step_axis +
+// ccindd_to_cc give: the neighbour at the level of the old cell (or the coarser leaf that covers it) comes from the
+// table; where finer cells lie behind the face the tree coordinates of the levels below are derived exactly as the
+// reference does (:1807-1837: 0 / base-1 on the crossed axis, int(b/csize_arr(j)) with the clamp and the MOD on the others).
+// cold: coordinates of the old cell's centre. Returns false when the walk fails (:1851); inside = false: ray left the model.
+#define DRT_NBR_OUT 0xFFFFFFFFu
+__device__ __forceinline__ bool next_cell(const DevProblem& P, const SrcInfo& S, Ray& r, int isel, double psel, double c0, double c1, double c2,
+                                          bool& inside)
+{
+    const int inc = (isel == 1) ? r.inc0 : (isel == 2) ? r.inc1 : r.inc2;
+    const uint32_t e = P.nbr[6ull * (unsigned long long)r.cc + 2 * (isel - 1) + (inc > 0 ? 1 : 0)];
+    inside = (e != DRT_NBR_OUT);
+    if (!inside) return true;
+    int l = (int)(e & 0x07FFFFFFu);
+    const int lv = (int)((e >> 27) & 15u);
+    if (!(e >> 31)) { r.cc = l; r.clvl = lv; return true; }
+    // finer cells behind the face (the table entry is at the old cell's own level)
+    double cellsize = P.csize_arr[r.clvl];
+    double b0 = psel / r.cpi0 + (S.sx - c0 + 0.5 * cellsize);
+    double b1 = psel / r.cpi1 + (S.sy - c1 + 0.5 * cellsize);
+    double b2 = psel / r.cpi2 + (S.sz - c2 + 0.5 * cellsize);
+    for (int j = lv + 1; j <= P.max_lvl; j++) {
+        const int ch = P.cchild[l];
+        if (ch == -1) { r.cc = l; r.clvl = j - 1; return true; }
+        const int b = (j > 1) ? P.base1 : P.base0;
+        cellsize = P.csize_arr[j];
+        int v0, v1, v2;
+        if (isel == 1) v0 = (inc == 1) ? 0 : b - 1;
+        else { v0 = (int)(b0 / cellsize); if (v0 == b) v0 = b - 1; b0 = (b0 >= 0) ? fmod_pos(b0, cellsize) : -fmod_pos(-b0, cellsize); }
+        if (isel == 2) v1 = (inc == 1) ? 0 : b - 1;
+        else { v1 = (int)(b1 / cellsize); if (v1 == b) v1 = b - 1; b1 = (b1 >= 0) ? fmod_pos(b1, cellsize) : -fmod_pos(-b1, cellsize); }
+        if (isel == 3) v2 = (inc == 1) ? 0 : b - 1;
+        else { v2 = (int)(b2 / cellsize); if (v2 == b) v2 = b - 1; b2 = (b2 >= 0) ? fmod_pos(b2, cellsize) : -fmod_pos(-b2, cellsize); }
+        l = ch + (v2 * b + v1) * b + v0;
+        if (l < 1 || l >= P.N) return false;
+    }
+    if (P.cchild[l] != -1) return false;
+    r.cc = l; r.clvl = P.max_lvl;
+    return true;
+}
+
 // check_wall_hit (rt_routines.f90:2572-2596)
 __device__ __forceinline__ bool wall_hit(const DevProblem& P, int rt, int cc)
 {
@@ -691,12 +732,9 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                 r.isel_old = isel;
                 r.clvl_old = r.clvl;
                 const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
-                const int clvl = r.clvl;
-                bool inside = step_axis(P, r.cx, r.inc0, isel == 1, clvl, psel, r.cpi0, S.sx, c[0]);
-                inside = inside && step_axis(P, r.cy, r.inc1, isel == 2, clvl, psel, r.cpi1, S.sy, c[1]);
-                inside = inside && step_axis(P, r.cz, r.inc2, isel == 3, clvl, psel, r.cpi2, S.sz, c[2]);
+                bool inside = true;
+                if (!next_cell(P, S, r, isel, psel, c[0], c[1], c[2], inside)) { err |= ERR_CELL_NOT_FOUND; busy = false; }
                 if (!inside) busy = false;
-                else if (!ccindd_to_cc(P, r.cx, r.cy, r.cz, r.cc, r.clvl)) { err |= ERR_CELL_NOT_FOUND; busy = false; }
             }
             TSTAMP(ts5);
             TACC(t_next, ts4, ts5);

@@ -603,12 +603,9 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 r.isel_old = isel;
                 r.clvl_old = r.clvl;
                 const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
-                const int clvl = r.clvl;
-                bool inside = step_axis(P, r.cx, r.inc0, isel == 1, clvl, psel, r.cpi0, S.sx, c[0]);
-                inside = inside && step_axis(P, r.cy, r.inc1, isel == 2, clvl, psel, r.cpi1, S.sy, c[1]);
-                inside = inside && step_axis(P, r.cz, r.inc2, isel == 3, clvl, psel, r.cpi2, S.sz, c[2]);
+                bool inside = true;
+                if (!next_cell(P, S, r, isel, psel, c[0], c[1], c[2], inside)) { err |= ERR_CELL_NOT_FOUND; busy = false; }
                 if (!inside) busy = false;
-                else if (!ccindd_to_cc(P, r.cx, r.cy, r.cz, r.cc, r.clvl)) { err |= ERR_CELL_NOT_FOUND; busy = false; }
             }
             TSTAMP(ts5);
             TACC(t_next, ts4, ts5);
