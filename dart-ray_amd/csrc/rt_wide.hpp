@@ -54,10 +54,16 @@ typedef __attribute__((address_space(3))) double ldouble;
 #ifdef DRT_I_GLOBAL
 typedef double* iptr_t;
 #define DRT_I_WORDS(L) 0
+#define IRD(p, i) gload((p) + (i))
 #else
 typedef ldouble* iptr_t;
 #define DRT_I_WORDS(L) (64 * (L))
+#define IRD(p, i) ((p)[i])
 #endif
+#ifndef DRT_OPQ
+#define DRT_OPQ 4  // wavelengths whose operands (dens, aux, intensity: 3 x 64 doubles each) are staged in LDS at a time
+#endif
+#define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ + 3)
 struct HotP {
     int L;
     double tau_thin, cs, en_lim;
@@ -272,7 +278,7 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
 template <int LP, bool BIG>
 __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
                               const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
-                              int* __restrict__ ostat, int level, iptr_t Ilds, double* __restrict__ thg, ldouble* ll, ldouble* bst,
+                              int* __restrict__ ostat, int level, iptr_t Ilds, double* __restrict__ thg, ldouble* ll, ldouble* bst, ldouble* opq,
                               const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc, int& err)
 {
     const int lane = lane_id();
@@ -524,53 +530,69 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 if (LP > 32) for (int off = 1; off < 64; off <<= 1) hi |= (unsigned)__shfl_xor((int)hi, off, 64);
                 unsigned long long lam_any = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)lo)
                                              | ((LP > 32) ? ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) : 0ull);
-                int l = lam_any ? __ffsll((long long)lam_any) - 1 : 0;
-                double dn = 0.0, ax = 1.0;
-                if (br != 0 && ((amask >> l) & 1ull)) { dn = gload(p_dens + l); ax = gload(p_aux + l * aux_stride); }
+                // Operands are fetched DRT_OPQ wavelengths at a time into LDS (dens, aux, ray intensity: three loads per
+                // wavelength and lane, issued together and waited for once). gfx950 has ONE in-order counter for loads and
+                // atomics: a load issued after a wavelength's atomics waits for all of them, so fetching per wavelength
+                // drained the atomic queue eleven times per step; per chunk it is two or three.
                 while (lam_any) {
-                    lam_any &= lam_any - 1;
-                    const int l1 = lam_any ? __ffsll((long long)lam_any) - 1 : l;  // the next wavelength to visit
-                    double dn1 = 0.0, ax1 = 1.0;
-                    if (lam_any && br != 0 && ((amask >> l1) & 1ull)) { dn1 = gload(p_dens + l1); ax1 = gload(p_aux + l1 * aux_stride); }
-                    const bool act = br != 0 && ((amask >> l) & 1ull);
-                    if (__ballot(act)) {
-                        TSTAMP(td0);
-#ifdef DRT_PROFILE
-                        wc.n_lam++;
-#endif
-                        double C = 0.0, U = 0.0;
-                        if (act) {
-                            double I = Ilds[l * 64 + lane];
-                            double e = 0.0, lost = 0.0;
-                            deposit_lambda(H, readlane_d(LT.ksca, l), rt, S, br, cc_s, l, length, dn, ax, beam_i, beam_f, csize_f, vol_f, I, U, e, lost, alive, wc);
-                            Ilds[l * 64 + lane] = I;
-                            if (lost != 0.0) (void)__hip_atomic_fetch_add(ll + l, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (e != 0.0) {
-                                C = e / ax;
-                                wc.sca++;
-                                wc.slots += (unsigned long long)__builtin_amdgcn_readlane(LT.np, l);
-                            }
+                    int lq[DRT_OPQ];
+                    unsigned long long mq = lam_any;
+#pragma unroll
+                    for (int q = 0; q < DRT_OPQ; q++) { lq[q] = mq ? __ffsll((long long)mq) - 1 : -1; mq &= mq - 1; }
+                    double tdn[DRT_OPQ], tax[DRT_OPQ], tI[DRT_OPQ];
+#pragma unroll
+                    for (int q = 0; q < DRT_OPQ; q++) {
+                        tdn[q] = 0.0; tax[q] = 1.0; tI[q] = 0.0;
+                        if (lq[q] >= 0 && br != 0 && ((amask >> lq[q]) & 1ull)) {
+                            tdn[q] = gload(p_dens + lq[q]); tax[q] = gload(p_aux + lq[q] * aux_stride); tI[q] = IRD(Ilds, lq[q] * 64 + lane);
                         }
-                        TSTAMP(td1);
-                        TACC(t_dep, td0, td1);
-                        if (a.scatter) {
-                            const unsigned long long MC = __ballot(C != 0.0);
-                            const unsigned long long M = MC | __ballot(U != 0.0);
-                            if (M) {
-                                // stage (C, U) of this wavelength for the uniform-address reads of flush_lambda; LDS
-                                // operations of one wave execute in issue order, the fences keep the compiler from
-                                // moving the reads of other lanes' values above these writes
-                                bst[lane] = C; bst[DRT_BST + lane] = U;
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                                flush_lambda<BIG>(P, M, MC, cc_s, U, bst, l, T, H, LT, wc);
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
+                    }
+#pragma unroll
+                    for (int q = 0; q < DRT_OPQ; q++) { opq[(3 * q) * 64 + lane] = tdn[q]; opq[(3 * q + 1) * 64 + lane] = tax[q]; opq[(3 * q + 2) * 64 + lane] = tI[q]; }
+#pragma nounroll
+                    for (int q = 0; q < DRT_OPQ && lam_any; q++) {
+                        const int l = __ffsll((long long)lam_any) - 1;
+                        lam_any &= lam_any - 1;
+                        const bool act = br != 0 && ((amask >> l) & 1ull);
+                        if (__ballot(act)) {
+                            TSTAMP(td0);
+#ifdef DRT_PROFILE
+                            wc.n_lam++;
+#endif
+                            double C = 0.0, U = 0.0;
+                            if (act) {
+                                const double dn = opq[(3 * q) * 64 + lane], ax = opq[(3 * q + 1) * 64 + lane];
+                                double I = opq[(3 * q + 2) * 64 + lane];
+                                double e = 0.0, lost = 0.0;
+                                deposit_lambda(H, readlane_d(LT.ksca, l), rt, S, br, cc_s, l, length, dn, ax, beam_i, beam_f, csize_f, vol_f, I, U, e, lost, alive, wc);
+                                Ilds[l * 64 + lane] = I;
+                                if (lost != 0.0) (void)__hip_atomic_fetch_add(ll + l, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (e != 0.0) {
+                                    C = e / ax;
+                                    wc.sca++;
+                                    wc.slots += (unsigned long long)__builtin_amdgcn_readlane(LT.np, l);
+                                }
+                            }
+                            TSTAMP(td1);
+                            TACC(t_dep, td0, td1);
+                            if (a.scatter) {
+                                const unsigned long long MC = __ballot(C != 0.0);
+                                const unsigned long long M = MC | __ballot(U != 0.0);
+                                if (M) {
+                                    // stage (C, U) of this wavelength for the uniform-address reads of flush_lambda; LDS
+                                    // operations of one wave execute in issue order, the fences keep the compiler from
+                                    // moving the reads of other lanes' values above these writes
+                                    bst[lane] = C; bst[DRT_BST + lane] = U;
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                    __builtin_amdgcn_wave_barrier();
+                                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                    flush_lambda<BIG>(P, M, MC, cc_s, U, bst, l, T, H, LT, wc);
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                    __builtin_amdgcn_wave_barrier();
+                                }
                             }
                         }
                     }
-                    dn = dn1; ax = ax1; l = l1;
                 }
             }
             if (br == 1) {
@@ -641,7 +663,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 // rt_loop + main_dir_loop (rt_routines.f90:985-1058, 1343-1467), ray-major. LP is the row stride of the
 // luminosity arrays in the queues (next power of two >= lnum); BIG: some slot table has more slots than lanes (kp >= 2),
 // the instantiation without it has no memory-table path in its deposit loop.
-// Dynamic LDS: per wave (DRT_I_WORDS(L) + LP + 5 * DRT_BST + 3) doubles.
+// Dynamic LDS: per wave DRT_LDS_WORDS(L, LP) doubles.
 template <int LP, bool BIG>
 __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
 {
@@ -654,8 +676,9 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     // then lives in scalar registers instead of 50+ vector registers that are spilled inside divergent code
     const int wib = first_lane_i((int)(threadIdx.x >> 6));
     const int gwave = blockIdx.x * waves_per_block + wib;
-    ldouble* ll = (ldouble*)lds_w + wib * (DRT_I_WORDS(L) + LP + 5 * DRT_BST + 3) + DRT_I_WORDS(L);
-    ldouble* bst = ll + LP;  // [5][DRT_BST]: C, U of the wavelength being flushed; nx, ny, nz of every ray; 
+    ldouble* ll = (ldouble*)lds_w + wib * DRT_LDS_WORDS(L, LP) + DRT_I_WORDS(L);
+    ldouble* bst = ll + LP;  // [5][DRT_BST]: C, U of the wavelength being flushed; nx, ny, nz of every ray;
+    ldouble* opq = bst + 5 * DRT_BST;  // [DRT_OPQ][3][64]: dens, aux, intensity of the wavelengths being deposited 
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
     const ArenaLayout AL = arena_layout(a.cap, a.hcap, LP);
@@ -763,7 +786,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
             }
             const ListView in = (mode == 0) ? Hc : Hn;
             const ListView oh = (mode == 0) ? Hn : Hc;
-            if (n_in > 0) trace_items_w<LP, BIG>(P, a, S, mode, in, n_in, oh, n_oh, LW, nL, ST, ostat, level, Ilds, thg, ll, bst, T, H, LT, wc, err);
+            if (n_in > 0) trace_items_w<LP, BIG>(P, a, S, mode, in, n_in, oh, n_oh, LW, nL, ST, ostat, level, Ilds, thg, ll, bst, opq, T, H, LT, wc, err);
             wave_fence();
             if (mode == 0) {
                 ListView t = Hc; Hc = Hn; Hn = t;
