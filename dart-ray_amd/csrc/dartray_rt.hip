@@ -339,7 +339,9 @@ extern "C" int drt_set_wavelengths(drt_ctx* c, int32_t lnum, const double* ksca,
     while (c->LP < lnum) c->LP <<= 1;
     // several wavelengths: a lane owns a ray and loops over its wavelengths (DRT_RAY_MAJOR=0 keeps lane = (ray, wavelength))
     const char* rm = getenv("DRT_RAY_MAJOR");
-    c->ray_major = (lnum >= 2) && !(rm && rm[0] == '0');
+    // DRT_RAY_MAJOR: unset = the ray-major kernel for every lnum; 0 = lane = (ray, wavelength) for every lnum; 2 = ray-major
+    // for lnum >= 2 only (the selection of round 1: one wavelength went to rt_stage_kernel<1>)
+    c->ray_major = !(rm && rm[0] == '0') && !(rm && rm[0] == '2' && lnum < 2);
     c->ksca.assign(ksca, ksca + lnum);
     c->gsca.assign(gsca, gsca + lnum);
     c->prepared = false;
@@ -540,6 +542,7 @@ static int ensure_arena(drt_ctx* c)
     if (c->waves <= 0 && c->ray_major) {
         int nb = 1;
         switch (c->LP) {
+        case 1: nb = wide_blocks_per_cu<1>(c); break;
         case 2: nb = wide_blocks_per_cu<2>(c); break;
         case 4: nb = wide_blocks_per_cu<4>(c); break;
         case 8: nb = wide_blocks_per_cu<8>(c); break;
@@ -943,9 +946,16 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if (blocks > c->waves / 4) blocks = c->waves / 4;
     a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
     a.task_first = 0; a.task_stride = 1;
+    // Phase window (trace_items_w): two cell sizes where deposits dominate; off where a source launches few rays (the
+    // work per source of the previous call of this stage, like the sectors per task) and the emptier steps cost more
+    // than the merged atomics save. DRT_PHASE_WINDOW overrides.
+    // (one wavelength, bench-sized grid: 0 -> 713 ms, 1 -> 848, 2 -> 753: not bound by the atomic unit; 32 wavelengths: 6.62 -> 5.99 s)
+    a.phase_win = (c->L >= 8 && c->G_want[rt_type & 15] != 4) ? 2.0 : 0.0;
+    if (const char* e = getenv("DRT_PHASE_WINDOW")) a.phase_win = atof(e);
     auto launch = [&](int nblocks) {
         if (c->ray_major) {
             switch (c->LP) {
+            case 1: launch_wide<1>(c, a, nblocks); break;
             case 2: launch_wide<2>(c, a, nblocks); break;
             case 4: launch_wide<4>(c, a, nblocks); break;
             case 8: launch_wide<8>(c, a, nblocks); break;

@@ -35,6 +35,8 @@ struct StageArgs {
     // Several ranks share the (source, sector) tasks of a point-source stage: this rank runs the tasks
     // task_first + k * task_stride (rt_routines.f90:1356-1358: the 48 sectors of a source are independent)
     int task_first, task_stride;
+    // phase-alignment window of the ray-major kernel in cell sizes (0 = every busy ray steps every time), see trace_items_w
+    double phase_win;
 };
 
 struct ListView {

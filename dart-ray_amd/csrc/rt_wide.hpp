@@ -21,9 +21,6 @@
                            // batch in phase (siblings cross the same cells in the same step -> more rays per atomic) and cost fewer
                            // set-up passes; measured 32: 1801 ms, 48: 1758, 64: 1738 (TRUST-I, 32 wavelengths, 21 801 cells)
 #endif
-#ifndef DRT_PHASE_K10
-#define DRT_PHASE_K10 20  // phase-alignment window of the ray-major kernel in tenths of a cell size (0 = off), see trace_items_w
-#endif
 #ifndef DRT_WIDE_WAVES
 #define DRT_WIDE_WAVES 3  // waves per SIMD the register allocator provisions for rt_stage_wide (168 registers; with the ray
                           // intensities in the arena LDS no longer caps the CU at 8 waves). Measured on the bench workload
@@ -475,13 +472,11 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
             // the memory-side atomic unit (bench: 1.99e10 64-byte requests/s = 1.27 TB/s): window 0 -> 6.62 s per step,
             // 1 cell size -> 6.14, 2 -> 5.99, 3 -> 6.39, 4 -> 6.52 (fewer atomics against more, emptier steps).
             bool go = busy;
-#if DRT_PHASE_K10 > 0
-            if (a.scatter) {
+            if (a.scatter && a.phase_win > 0.0) {
                 double pm = busy ? r.prev : 1.0e300;
                 for (int off = 1; off < 64; off <<= 1) pm = fmin(pm, __shfl_xor(pm, off, 64));
-                go = busy && (r.prev <= pm + (0.1 * DRT_PHASE_K10) * P.csize_arr[r.clvl]);
+                go = busy && (r.prev <= pm + a.phase_win * P.csize_arr[r.clvl]);
             }
-#endif
             if (go) {
                 wc.inter++;
                 calc_psel(P, S, r, psel, isel);

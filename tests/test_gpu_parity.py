@@ -39,14 +39,11 @@ def relelem(a, b):
 @pytest.mark.parametrize("mapping", ["ray_major", "lane_per_wavelength"])
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_gpu_matches_reference_golden(name, mapping, golden, pkg, monkeypatch):
-    """Both lane mappings of the stage kernel: rt_stage_wide (lane = ray, used when the case has
-    several wavelengths) and rt_stage_kernel (lane = (ray, wavelength), DRT_RAY_MAJOR=0) against the reference's
-    own output."""
+    """Both lane mappings of the stage kernel: rt_stage_wide (lane = ray, the default for every number
+    of wavelengths) and rt_stage_kernel (lane = (ray, wavelength), DRT_RAY_MAJOR=0) against the reference's own output."""
     z, path = golden(name)
     case = pkg.grids.read_case(path, name)
     if mapping == "lane_per_wavelength":
-        if case.lnum < 2:
-            pytest.skip("one wavelength: both mappings are the same kernel")
         monkeypatch.setenv("DRT_RAY_MAJOR", "0")
     g = pkg.DartRayGPU(case)
     g.rt_prepare("start")
