@@ -99,4 +99,4 @@ def test_fortran_main_reads_the_references_input_files():
                       ("MAGTAR_GRIDS/input_shell.in", "grid_shell.h5")):
         out = subprocess.run([exe, inp], cwd=ref, capture_output=True, text=True, timeout=60)
         assert out.returncode != 0
-        assert "main grid file not found" in out.stdout + out.stderr and grid in out.stdout + out.stderr
+        assert "file not found" in out.stdout + out.stderr and grid in out.stdout + out.stderr   # check_input
