@@ -201,6 +201,7 @@ module dartray_state
   real(kind=real64) :: x_wall_coord(2), y_wall_coord(2), z_wall_coord(2)
   integer :: rt_type, iterations, max_sca_iterations, np_mpi, id_mpi
   logical :: main_prc
+  logical :: file_restore = .FALSE., file_restore_part1 = .FALSE.        ! io_routines.f90:137-140, set by check_files
   ! rt_type ids, rt_routines.f90:195-217
   integer, parameter :: rtt_start = 0, rtt_precalc_cell = 1, rtt_precalc_src = 2, rtt_output_part1 = 3, &
        rtt_prep_part2 = 4, rtt_dir_cell = 5, rtt_i_obs_dir_cell = 6, rtt_dir_src = 7, rtt_i_obs_dir_src = 8, &
@@ -237,6 +238,15 @@ module dartray_hub_gpu
   !> Called where dartray_main calls make_output (dartray_hub.f90:27,43,52,59); the reference's HDF5
   !> writers (io_routines.f90:1743) plug in here, the module arrays are up to date at that point.
   procedure(output_hook), pointer :: make_output => null()
+  !> Stage restart (dartray_hub.f90:397-417): check_files (io_routines.f90:893) decides what can be restored and sets
+  !> file_restore / file_restore_part1; read_output (io_routines.f90:1900, case rtt_start) fills u_fest_arr, or u_final_arr,
+  !> scaspe_arr, lum_lost and i_obs_arr, from the files of an earlier run. Left null, every run starts from the beginning.
+  procedure(output_hook), pointer :: check_files => null(), read_output => null()
+#ifdef DRT_REAL_MODULES
+  ! io_routines.f90:137-140; that module needs the HDF5 Fortran modules, which amdflang cannot read in this image, so the
+  ! link test keeps the two flags here
+  logical :: file_restore = .FALSE., file_restore_part1 = .FALSE.
+#endif
 contains
 
   !> Error convention of the reference: print + stop (stop_prc, smooth_grid_routines.f90:869-892).
@@ -315,6 +325,22 @@ contains
           npix_arr(i) = a; npix_hp_arr(i) = b; kp_sca_arr(i) = c
        enddo
        iterations = 0
+       if (associated(check_files)) call check_files()
+       if (file_restore_part1) then
+          ! u_fest of an earlier run instead of the two precalculation stages; the stage machine goes on at prep_part2
+          if (.not. allocated(u_fest_arr)) allocate(u_fest_arr(0:lnum-1, 0:tot_ncell-1))
+          call read_output()
+          call gpu_check(drt_set_array(gpu_ctx, DRT_A_U_FEST, 0, u_fest_arr, int(lnum, c_size_t)*int(tot_ncell, c_size_t)), 'u_fest_arr')
+          rt_type = rtt_output_part1
+       endif
+       if (file_restore) then
+          ! the direct-light fields of an earlier run; the stage machine goes on at the scattering iterations
+          call gpu_check(drt_rt_prepare(gpu_ctx, rtt_prep_part2), 'rt_prepare(prep_part2)')     ! create_scaspe, create_i_obs
+          call gpu_alloc_part2
+          call read_output()
+          call gpu_restore_part2
+          rt_type = rtt_output_part2
+       endif
     case (rtt_prep_part2)
        call gpu_check(drt_rt_prepare(gpu_ctx, rtt_prep_part2), 'rt_prepare(prep_part2)')
     case (rtt_scatt)
@@ -331,6 +357,36 @@ contains
        stop 1
     end select
   end subroutine rt_prepare
+
+  !> The module arrays read_output fills when file_restore is set (create_scaspe, create_i_obs; u_final_arr and lum_lost
+  !> exist from grid_initialize in the reference).
+  subroutine gpu_alloc_part2()
+    integer :: i
+    if (.not. allocated(u_final_arr)) allocate(u_final_arr(0:lnum-1, 0:tot_ncell-1))
+    if (.not. allocated(lum_lost)) allocate(lum_lost(0:lnum-1))
+    if (.not. allocated(scaspe_arr)) then
+       allocate(scaspe_arr(0:lnum-1))
+       do i = 0, lnum-1
+          allocate(scaspe_arr(i)%a(0:npix_arr(i)-1, 0:tot_ncell-1))
+       enddo
+    endif
+    if (tot_ndir > 0 .and. .not. allocated(i_obs_arr)) allocate(i_obs_arr(0:lnum-1, 0:tot_ncell+tot_p_src-1, 0:tot_ndir-1))
+  end subroutine gpu_alloc_part2
+
+  !> Upload of what read_output restored (the reverse of gpu_sync_to_host(rtt_output_part2)).
+  subroutine gpu_restore_part2()
+    integer :: i
+    integer(c_size_t) :: n
+    n = int(lnum, c_size_t)*int(tot_ncell, c_size_t)
+    call gpu_check(drt_set_array(gpu_ctx, DRT_A_U_FINAL, 0, u_final_arr, n), 'u_final_arr')
+    call gpu_check(drt_set_array(gpu_ctx, DRT_A_LUM_LOST, 0, lum_lost, int(lnum, c_size_t)), 'lum_lost')
+    do i = 0, lnum-1
+       call gpu_check(drt_set_array(gpu_ctx, DRT_A_SCASPE, int(i, c_int32_t), scaspe_arr(i)%a, &
+            int(npix_arr(i), c_size_t)*int(tot_ncell, c_size_t)), 'scaspe_arr')
+    enddo
+    if (tot_ndir > 0) call gpu_check(drt_set_array(gpu_ctx, DRT_A_I_OBS, 0, i_obs_arr, &
+         int(lnum, c_size_t)*int(tot_ncell+tot_p_src, c_size_t)*int(tot_ndir, c_size_t)), 'i_obs_arr')
+  end subroutine gpu_restore_part2
 
   !> rt_loop (rt_routines.f90:985): the source loop, ray fan, traversal and deposition, on the GPU.
   subroutine rt_loop()

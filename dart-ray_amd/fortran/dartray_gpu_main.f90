@@ -34,6 +34,8 @@ program dartray_gpu_main
   endif
   call gpu_grid_initialize
   make_output => make_output_hdf5
+  check_files => check_files_hdf5
+  read_output => read_output_hdf5
   call dartray_main
   call gpu_finalize
   print '(a,i0,a)', 'dartray_gpu_main: done, ', iterations, ' scattering iterations'

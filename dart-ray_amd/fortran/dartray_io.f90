@@ -40,6 +40,13 @@ module dartray_io_c
        integer(c_int64_t), intent(in) :: fdims(*)
        real(c_double), intent(in) :: data(*)
      end function drt_io_write_array
+     integer(c_int) function drt_io_read_array(path, dsetname, rank, fdims, data) bind(C, name='drt_io_read_array')
+       import :: c_int, c_char, c_int64_t, c_double
+       character(kind=c_char), intent(in) :: path(*), dsetname(*)
+       integer(c_int), value :: rank
+       integer(c_int64_t), intent(in) :: fdims(*)
+       real(c_double), intent(out) :: data(*)
+     end function drt_io_read_array
      integer(c_int) function drt_io_add_int(path, dsetname, v) bind(C, name='drt_io_add_int')
        import :: c_int, c_char, c_int32_t
        character(kind=c_char), intent(in) :: path(*), dsetname(*)
@@ -632,6 +639,97 @@ contains
        path = trim(path)//fname(i)
     enddo
   end subroutine out_name
+
+  logical function out_exists(lambda, what)
+    real(kind=real64), intent(in) :: lambda
+    character(len=*), intent(in) :: what
+    character(len=3*lcar) :: path
+    call out_name(lambda, what, path)
+    inquire(file=trim(path), exist=out_exists)
+  end function out_exists
+
+  !> check_files (io_routines.f90:893-1102): a final output file that exists already stops the run; otherwise, with
+  !> restore_file_mpi set, a complete set of part-2 files (u_final, scaspe, i_obs, lum_lost after the direct light) makes
+  !> the run start at the scattering iterations (file_restore), and failing that a complete set of part-1 files (u_fest)
+  !> makes it start at the direct light (file_restore_part1).
+  subroutine check_files_hdf5()
+    integer :: i
+    logical :: all_there
+    file_restore = .FALSE.; file_restore_part1 = .FALSE.
+    do i = 0, lnum-1
+       if (out_exists(lambda_arr(i), 'ufield')) call stop_prc('STOP(check_files): the u_final output file exists already')
+       if (use_dir_out) then
+          if (out_exists(lambda_arr(i), 'i_obs')) call stop_prc('STOP(check_files): the i_obs output file exists already')
+       endif
+       if (print_scaspe_tot) then
+          if (out_exists(lambda_arr(i), 'scaspe_tot')) call stop_prc('STOP(check_files): the scaspe_tot output file exists already')
+       endif
+    enddo
+    if (out_exists(-1.0_real64, 'lum_lost')) call stop_prc('STOP(check_files): the lum_lost output file exists already')
+    all_there = .TRUE.
+    do i = 0, lnum-1
+       if (.not. out_exists(lambda_arr(i), 'ufield_part2')) all_there = .FALSE.
+       if (.not. out_exists(lambda_arr(i), 'scaspe_part2')) all_there = .FALSE.
+       if (use_dir_out) then
+          if (.not. out_exists(lambda_arr(i), 'i_obs_part2')) all_there = .FALSE.
+       endif
+    enddo
+    if (.not. out_exists(-1.0_real64, 'lum_lost_part2')) all_there = .FALSE.
+    if (all_there .and. restore_file_mpi) then
+       file_restore = .TRUE.
+       print *, 'Intermediate files will be restored'
+       return
+    endif
+    all_there = .TRUE.
+    do i = 0, lnum-1
+       if (.not. out_exists(lambda_arr(i), 'u_fest_part1')) all_there = .FALSE.
+    enddo
+    if (all_there .and. restore_file_mpi) then
+       file_restore_part1 = .TRUE.
+       print *, 'Output part 1 will be restored!'
+    endif
+  end subroutine check_files_hdf5
+
+  !> read_output, case rtt_start (io_routines.f90:1907-1957) through read_big_array (:2003): the inverse of
+  !> make_output_hdf5 for the part-1 or part-2 files; the arrays are allocated by the caller (rt_prepare).
+  subroutine read_output_hdf5()
+    character(len=3*lcar) :: path
+    integer :: i
+    integer(c_int64_t) :: d1(1), d2(2)
+    real(kind=real64), allocatable :: tmp(:), tmp2(:,:)
+    allocate(tmp(0:tot_ncell-1))
+    d1 = tot_ncell
+    if (file_restore) then
+       print *, 'restoring output part2...'
+       do i = 0, lnum-1
+          call out_name(lambda_arr(i), 'ufield_part2', path)
+          call io_check(drt_io_read_array(cstr(path), cstr('u_final'), 1, d1, tmp), 'read_ufield_arr')
+          u_final_arr(i,:) = tmp
+          d2 = [int(npix_arr(i), c_int64_t), int(tot_ncell, c_int64_t)]
+          call out_name(lambda_arr(i), 'scaspe_part2', path)
+          call io_check(drt_io_read_array(cstr(path), cstr('scaspe'), 2, d2, scaspe_arr(i)%a), 'read_scaspe_arr')
+          if (tot_ndir > 0) then
+             allocate(tmp2(0:tot_ncell+tot_p_src-1, 0:tot_ndir-1))
+             d2 = [int(tot_ncell+tot_p_src, c_int64_t), int(tot_ndir, c_int64_t)]
+             call out_name(lambda_arr(i), 'i_obs_part2', path)
+             call io_check(drt_io_read_array(cstr(path), cstr('i_obs'), 2, d2, tmp2), 'read_i_obs_arr')
+             i_obs_arr(i,:,:) = tmp2
+             deallocate(tmp2)
+          endif
+       enddo
+       d1 = lnum
+       call out_name(-1.0_real64, 'lum_lost_part2', path)
+       call io_check(drt_io_read_array(cstr(path), cstr('lum_lost'), 1, d1, lum_lost), 'read_lum_lost')
+    endif
+    if (file_restore_part1) then
+       print *, 'restoring output part 1...'
+       do i = 0, lnum-1
+          call out_name(lambda_arr(i), 'u_fest_part1', path)
+          call io_check(drt_io_read_array(cstr(path), cstr('u_fest'), 1, d1, tmp), 'read_u_fest_arr')
+          u_fest_arr(i,:) = tmp
+       enddo
+    endif
+  end subroutine read_output_hdf5
 
   !> make_output (io_routines.f90:1743-1897) through print_big_array (:1112): one HDF5 file per array and wavelength
   subroutine make_output_hdf5()

@@ -150,7 +150,8 @@ def write_outputs(gpu, label: str, lambdas, out_dir: str, stage: str) -> None:
         write_array(j(filename(label, -1.0, "sed_dir" if part2 else "sed")), "sed_arr_dir" if part2 else "sed_arr", [L, ndir], gpu.sed())
 
 
-def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_lambda_grid: bool = True, iref: int = 0) -> str:
+def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_lambda_grid: bool = True, iref: int = 0,
+                           restore_file_mpi: bool = False) -> str:
     """Write `case` (grids.Case) as the set of files the reference's main programs read (and
     dart-ray_amd/fortran/dartray_gpu_main reads): <root>/GRIDS/ with the HDF5 main grid, one lambda grid per
     wavelength, the wavelength list, dir_out and point-source files, an effective-opacity table in the layout
@@ -158,7 +159,9 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_l
     <root>/input.in with the three namelists. Returns the path of input.in.
     use_lambda_grid = False leaves the per-wavelength grids out: the run then scales the main grid's dens with
     kext(lambda)/kext(lambda_ref) from the opacity table (scale_dens_arr, rt_routines.f90:5018), which needs a case whose
-    dens columns are multiples of each other and which has no diffuse stellar emission."""
+    dens columns are multiples of each other and which has no diffuse stellar emission.
+    restore_file_mpi: the run may start from the part-1 / part-2 files of an earlier run found in <root>/RUNS
+    (check_files, io_routines.f90:893)."""
     lambdas = [float(x) for x in lambdas]
     L = case.lnum
     assert len(lambdas) == L and all(b > a for a, b in zip(lambdas, lambdas[1:]))
@@ -223,7 +226,7 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_l
         f.write("&dartray_input_logical\n"
                 f"use_lambda_grid = {fl(use_lambda_grid)},\nuse_dir_out = {fl(ndir > 0)},\nuse_p_src = {fl(nsrc > 0)},\nprint_output_part1 = .TRUE.,\n"
                 "print_output_part2 = .TRUE.,\nprint_scaspe_part2 = .TRUE.,\nprint_scaspe_tot = .TRUE.,\nprint_sed = .TRUE.,\n"
-                "input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\n"
+                f"input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\nrestore_file_mpi = {fl(restore_file_mpi)},\n"
                 f"x_wall_on = {fl(case.wall_on[0])},\ny_wall_on = {fl(case.wall_on[1])},\nz_wall_on = {fl(case.wall_on[2])},\n"
                 f"limit_scattering_iterations = {fl(case.max_sca_iterations >= 0)}\n/\n")
     return inp

@@ -444,6 +444,63 @@ def test_fortran_main_scales_the_main_grid_like_scale_dens_arr(pkg, tmp_path):
     g.close()
 
 
+def test_fortran_main_restarts_from_the_files_of_an_earlier_run(pkg, tmp_path):
+    """Stage restart (rt_prepare, dartray_hub.f90:397-417; check_files, io_routines.f90:893; read_output :1900): with
+    restore_file_mpi set, a run that finds the part-2 files (u_final, scaspe, i_obs, lum_lost after the direct light)
+    starts at the scattering iterations, one that finds only the part-1 files (u_fest) starts at the direct light, and
+    both end with the fields of the uninterrupted run; a run that finds final output files stops before it overwrites
+    them."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "fortran", "dartray_gpu_main")
+    if not os.path.exists(exe) or not os.path.exists(pkg.io.LIB_PATH):
+        pytest.skip("Fortran main program / HDF5 library not built")
+    idx = [8, 14]
+    lambdas = [float(pkg.grids.TRUSTI_TABLE[i, 0]) for i in idx]
+    case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=2, wavelengths=idx, max_sca_iterations=2)
+    N, ndir, L = case.tree.ncell, case.dir_out.shape[0], case.lnum
+
+    def run(sub, restore, keep=()):
+        root = str(tmp_path / sub)
+        inp = pkg.io.write_reference_inputs(case, lambdas, root, label="slab", restore_file_mpi=restore)
+        for pat in keep:
+            for f in glob.glob(os.path.join(str(tmp_path / "full"), "RUNS", pat)):
+                shutil.copy(f, os.path.join(root, "RUNS"))
+        out = subprocess.run([exe, inp], capture_output=True, text=True, timeout=300)
+        return root, out
+
+    def fields(root):
+        f = lambda lam, what: os.path.join(root, "RUNS", pkg.io.filename("slab", lam, what))
+        r = {"sed": pkg.io.read_array(f(-1.0, "sed"), "sed_arr", [L, ndir]), "lum_lost": pkg.io.read_array(f(-1.0, "lum_lost"), "lum_lost", [L])}
+        for il, lam in enumerate(lambdas):
+            r["u", il] = pkg.io.read_array(f(lam, "ufield"), "u_final", [N])
+        return r, f
+
+    root, out = run("full", False)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "restor" not in out.stdout
+    ref, f = fields(root)
+    # a second run on the same directory must not overwrite the final files
+    out = subprocess.run([exe, os.path.join(root, "input.in")], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "exists already" in out.stdout
+    for sub, keep, msg in (("from_part2", ("*part2*", "*part1*"), "Intermediate files will be restored"),
+                           ("from_part1", ("*part1*",), "Output part 1 will be restored")):
+        root, out = run(sub, True, keep)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert msg in out.stdout, out.stdout[-2000:]
+        got, _ = fields(root)
+        for k in ref:
+            tol = 1e-7 if k == "lum_lost" else 1e-9 if k == "sed" else RTOL
+            assert relmax(got[k], ref[k]) <= tol, (sub, k)
+    # restore_file_mpi unset: the files are there but the run starts from the beginning (and still ends the same)
+    root, out = run("no_restore", False, ("*part1*",))
+    assert out.returncode == 0 and "restored" not in out.stdout
+    got, _ = fields(root)
+    assert relmax(got["u", 0], ref["u", 0]) <= RTOL
+
+
 @pytest.mark.parametrize("name", ["magtar_shell", "galaxy", "nbody"])
 def test_baseline_configs_at_their_wavelength_counts(name, pkg):
     """BASELINE configs 3-5 with as many wavelengths per ray as the survey gives them, at sizes the oracle cannot reach:
