@@ -99,7 +99,8 @@ struct drt_ctx {
     uint32_t* d_nbr = nullptr;
     double *d_ccoord = nullptr, *d_csize = nullptr, *d_dens = nullptr, *d_u_fest = nullptr, *d_u_final = nullptr, *d_lumcell = nullptr;
     double *d_p_src_pos = nullptr, *d_p_src_lum = nullptr, *d_dir_out = nullptr, *d_lum_lost = nullptr, *d_lum_lost_prev = nullptr;
-    double *d_i_obs = nullptr, *d_tot = nullptr;
+    double *d_i_obs = nullptr, *d_tot = nullptr, *d_src_cost = nullptr;
+    std::vector<double> src_cost_h;  // d_src_cost as build_src_list last read it
     std::vector<double*> d_scaspe, d_scaspe_prev, d_scaspe_tot, d_tab;
     DevProblem* d_prob = nullptr;
     DevProblem hprob{};
@@ -112,6 +113,11 @@ struct drt_ctx {
     char* d_spawn = nullptr;
     int spawn_cap = 0;
     size_t src_list_cap = 0;
+    int2* d_heavy = nullptr;
+    size_t heavy_cap = 0;
+    int* d_deep = nullptr;
+    size_t deep_cap = 0;
+    bool overflow_met = false;
     int* d_dbg = nullptr;
     int dbg_cap = 0, dbg_flags = 0;
     double* d_ring_tab[14] = {nullptr}, *d_phi0_tab[14] = {nullptr}, *d_phi1_tab[14] = {nullptr};
@@ -206,7 +212,7 @@ extern "C" int drt_destroy(drt_ctx* c)
     free_fields(c);
     void* ptrs[] = {c->d_nbr, c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
                     c->d_u_final, c->d_lumcell, c->d_p_src_pos, c->d_p_src_lum, c->d_dir_out, c->d_lum_lost, c->d_lum_lost_prev,
-                    c->d_i_obs, c->d_tot, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter,
+                    c->d_i_obs, c->d_tot, c->d_src_cost, c->d_heavy, c->d_deep, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter,
                     c->d_bak_lost, c->d_bak_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
@@ -504,7 +510,7 @@ static int upload_problem(drt_ctx* c)
         P.utab_np[u] = (u < (int)c->npix_unique.size()) ? c->npix_unique[u] : 0;
     }
     P.arena = c->d_arena;
-    P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task;
+    P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task; P.src_cost = c->d_src_cost;
     P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap; P.dbg_flags = c->dbg_flags;
     for (int k = 0; k < 14; k++) { P.ring_tab[k] = c->d_ring_tab[k]; P.phi0_tab[k] = c->d_phi0_tab[k]; P.phi1_tab[k] = c->d_phi1_tab[k]; }
     P.tab_max_level = c->tab_max_level;
@@ -695,6 +701,7 @@ static int prepare_start(drt_ctx* c)
     if ((rc = dev_zero(c, &c->d_u_final, (size_t)N * L))) return rc;
     if ((rc = dev_zero(c, &c->d_lum_lost, (size_t)L))) return rc;
     if ((rc = dev_zero(c, &c->d_lum_lost_prev, (size_t)L))) return rc;
+    if ((rc = dev_zero(c, &c->d_src_cost, (size_t)N))) return rc;
     free_fields(c);
     c->iterations = 0; c->cnflag = 0; c->bm_par_cur = c->par.bm_par; c->part2 = false;
     c->prepared = true;
@@ -855,10 +862,49 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list)
         if (!iobs && !psrc && by_mod && (i % np) != id) continue;
         list.push_back(i);
     }
+    // the wave time every source took in the previous cell-source launch, summed over the ranks by rt_mpi
+    if (!iobs && !psrc && c->d_src_cost) {
+        c->src_cost_h.resize((size_t)N);
+        HIPCHK(c, hipMemcpy(c->src_cost_h.data(), c->d_src_cost, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+    }
     if (!iobs && !psrc && !by_mod && np > 1) {
         const size_t n = list.size();
         std::vector<int> mine;
-        if (by_block) {
+        size_t known = 0;
+        double csum = 0;
+        for (int i : list) if (c->src_cost_h[(size_t)i] > 0) { known++; csum += c->src_cost_h[(size_t)i]; }
+        const bool by_cost = !by_block && !(pe && !strcmp(pe, "cyclic")) && known * 2 > n;
+        if (by_cost) {
+            // Longest-processing-time deal of chunks of consecutive sources, by measured cost: the chunks keep neighbours
+            // together, a source that costs more than 1/64 of a rank's share is a chunk of its own; heaviest chunk first to
+            // the least loaded rank (ties: lower rank). Every rank computes the same deal from the same (all-reduced) costs.
+            const double mean = csum / (double)known, big = csum / np / 64.0;
+            struct Chunk { size_t lo, hi; double cost; };
+            std::vector<Chunk> ch;
+            for (size_t k = 0; k < n;) {
+                Chunk q{k, k, 0.0};
+                while (q.hi < n && q.hi - q.lo < chunk) {
+                    double v = c->src_cost_h[(size_t)list[q.hi]];
+                    if (!(v > 0)) v = mean;
+                    if (v > big) { if (q.hi == q.lo) { q.cost = v; q.hi++; } break; }
+                    q.cost += v; q.hi++;
+                }
+                ch.push_back(q);
+                k = q.hi;
+            }
+            std::vector<size_t> order(ch.size());
+            for (size_t k = 0; k < order.size(); k++) order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return ch[x].cost > ch[y].cost; });
+            std::vector<double> load((size_t)np, 0.0);
+            std::vector<char> take(ch.size(), 0);
+            for (size_t k : order) {
+                int r = 0;
+                for (int q = 1; q < np; q++) if (load[(size_t)q] < load[(size_t)r]) r = q;
+                load[(size_t)r] += ch[k].cost;
+                if (r == id) take[k] = 1;
+            }
+            for (size_t k = 0; k < ch.size(); k++) if (take[k]) mine.insert(mine.end(), list.begin() + ch[k].lo, list.begin() + ch[k].hi);
+        } else if (by_block) {
             const size_t lo = n * (size_t)id / np, hi = n * (size_t)(id + 1) / np;
             mine.assign(list.begin() + lo, list.begin() + hi);
         } else {
@@ -930,6 +976,8 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     const int64_t inter_before = c->cnt.intersections;  // the device counters run on until drt_reset_counters
     c->cnt.sources = (int64_t)list.size();
     c->cnt.kernel_ms = 0; c->cnt.launches = 0;
+    const bool cell_stage = !(rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC);
+    if (cell_stage) HIPCHK(c, hipMemset(c->d_src_cost, 0, (size_t)c->N * sizeof(double)));  // build_src_list has read the previous launch's
     if (list.empty()) return DRT_OK;
     if ((rc = ensure_arena(c))) return rc;
     if (c->hprob.arena != c->d_arena || c->hprob.bm_par != c->bm_par_cur) if ((rc = upload_problem(c))) return rc;
@@ -946,6 +994,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if (blocks > c->waves / 4) blocks = c->waves / 4;
     a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
     a.task_first = 0; a.task_stride = 1;
+    a.heavy = nullptr; a.n_heavy = 0; a.record_cost = cell_stage ? 1 : 0;
     // Phase window (trace_items_w): two cell sizes where deposits dominate; off where a source launches few rays (the
     // work per source of the previous call of this stage, like the sectors per task) and the emptier steps cost more
     // than the merged atomics save. DRT_PHASE_WINDOW overrides.
@@ -1010,50 +1059,65 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         return DRT_OK;
     };
     HIPCHK(c, hipEventRecord(c->ev0, 0));
-    if (psrc) {
-        // few, deep sources: sub-tree tasks (StageArgs::export_level). Phase 1 exports at most 192 rays per source.
-        const int need = 192 * (int)list.size();
+    // Sub-tree tasks (StageArgs::export_level) for the `nsub` sources of `sub_list` (device): phase 1 traces their 192 nside-4
+    // rays, one sector per task, and exports the blocked ones (at most 192 per source); phase 2 runs one task per child pixel
+    // of an exported ray. `first`/`stride`: the phase-1 tasks this rank takes. ovf: a queue overflowed (state to be restored).
+    auto subtree = [&](const int* sub_list, int nsub, int first, int stride, int max_blocks, bool& ovf, bool& retry_fewer) -> int {
+        ovf = false; retry_fewer = false;
+        const int need = 192 * nsub;
         if (need > c->spawn_cap || !c->d_spawn) {
             if (c->d_spawn) (void)hipFree(c->d_spawn);
             c->spawn_cap = need;
             HIPCHK(c, hipMalloc((void**)&c->d_spawn, list_bytes(need, c->LP) + 4ull * need));
         }
         if (!c->d_spawn_counter) HIPCHK(c, hipMalloc((void**)&c->d_spawn_counter, sizeof(int)));
+        StageArgs keep = a;
+        a.src_list = sub_list; a.nsources = nsub; a.sectors_per_task = 1; a.heavy = nullptr; a.n_heavy = 0;
         a.spawn = c->d_spawn; a.spawn_cap = c->spawn_cap; a.spawn_counter = c->d_spawn_counter;
-        for (int max_blocks = c->waves / 4;; max_blocks = (max_blocks + 1) / 2) {
-            if ((rc = copy_state(true))) return rc;
-            HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
-            a.export_level = 4; a.spawn_count = 0;
-            a.task_first = c->par.id_mpi; a.task_stride = c->par.np_mpi;  // the sector tasks of phase 1 are dealt round the ranks
-            const int blocks1 = std::max(1, std::min(blocks, max_blocks));
-            if ((rc = carve_arena(c, blocks1 * 4, a))) {  // not even 64-ray queues for this many waves: use fewer
-                if (rc == DRT_E_CAPACITY && blocks1 > 1) { max_blocks = blocks1; continue; }
-                return rc;
-            }
+        HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
+        a.export_level = 4; a.spawn_count = 0;
+        a.task_first = first; a.task_stride = stride;
+        const long long nt1 = 48ll * nsub;
+        const int blocks1 = (int)std::max(1ll, std::min((nt1 + 3) / 4, (long long)max_blocks));
+        int rc2 = carve_arena(c, blocks1 * 4, a);
+        if (rc2) {  // not even 64-ray queues for this many waves: use fewer
+            a = keep;
+            if (rc2 == DRT_E_CAPACITY && blocks1 > 1) { retry_fewer = true; return DRT_OK; }
+            return rc2;
+        }
+        HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+        launch(blocks1);
+        c->cnt.launches++;
+        int nspawn = 0;
+        HIPCHK(c, hipMemcpy(&nspawn, c->d_spawn_counter, sizeof(int), hipMemcpyDeviceToHost));
+        if ((rc2 = overflowed(ovf))) { a = keep; return rc2; }
+        if (!ovf && nspawn > 0) {
+            a.export_level = 0; a.spawn_count = std::min(nspawn, c->spawn_cap);
+            a.task_first = 0; a.task_stride = 1;  // phase 2 runs what THIS rank exported
+            const long long nt = 4ll * a.spawn_count;
+            int blocks2 = (int)std::max(1ll, std::min((nt + 3) / 4, (long long)max_blocks));
+            while ((rc2 = carve_arena(c, blocks2 * 4, a)) == DRT_E_CAPACITY && blocks2 > 1) blocks2 = (blocks2 + 1) / 2;
+            if (rc2) { a = keep; return rc2; }
             HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-            HIPCHK(c, hipEventRecord(c->ev0, 0));
-            launch(blocks1);
+            launch(blocks2);
             c->cnt.launches++;
-            int nspawn = 0;
-            HIPCHK(c, hipMemcpy(&nspawn, c->d_spawn_counter, sizeof(int), hipMemcpyDeviceToHost));
-            bool ovf = false;
-            if ((rc = overflowed(ovf))) return rc;
-            int blocks2 = 0;
-            if (!ovf && nspawn > 0) {
-                a.export_level = 0; a.spawn_count = std::min(nspawn, c->spawn_cap);
-                a.task_first = 0; a.task_stride = 1;  // phase 2 runs what THIS rank exported
-                const long long nt = 4ll * a.spawn_count;
-                blocks2 = (int)std::max(1ll, std::min((nt + 3) / 4, (long long)max_blocks));
-                while ((rc = carve_arena(c, blocks2 * 4, a)) == DRT_E_CAPACITY && blocks2 > 1) blocks2 = (blocks2 + 1) / 2;
-                if (rc) return rc;
-                HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-                launch(blocks2);
-                c->cnt.launches++;
-                if ((rc = overflowed(ovf))) return rc;
-            }
+            if ((rc2 = overflowed(ovf))) { a = keep; return rc2; }
+        }
+        a = keep;
+        return DRT_OK;
+    };
+    if (psrc) {
+        // few, deep sources; the sector tasks of phase 1 are dealt round the ranks
+        for (int max_blocks = c->waves / 4;;) {
+            if ((rc = copy_state(true))) return rc;
+            HIPCHK(c, hipEventRecord(c->ev0, 0));
+            bool ovf = false, fewer = false;
+            if ((rc = subtree(c->d_src_list, (int)list.size(), c->par.id_mpi, c->par.np_mpi, max_blocks, ovf, fewer))) return rc;
+            if (fewer) { max_blocks = std::max(1, std::min(max_blocks, (int)((48ll * (long long)list.size() + 3) / 4)) / 2); continue; }
             if (!ovf) break;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
             if (max_blocks <= 1) return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
+            max_blocks = (max_blocks + 1) / 2;
         }
     } else {
         // Cell sources: G sectors per task. More sectors fill the lanes better (and merge more rays per atomic) but
@@ -1068,28 +1132,87 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         Gtry = std::min(Gtry, G);
         if (const char* e = getenv("DRT_SECTORS_PER_TASK")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = std::min(Gtry, v); }
         int max_blocks = c->waves / 4;
-        for (;;) {
-            a.sectors_per_task = Gtry;
-            ntasks = (long long)list.size() * (48 / Gtry);
-            blocks = (int)std::max(1ll, std::min((ntasks + 3) / 4, (long long)max_blocks));
-            if ((rc = carve_arena(c, blocks * 4, a))) {  // not even 64-ray queues for this many waves: use fewer
-                if (rc == DRT_E_CAPACITY && blocks > 1) { max_blocks = (blocks + 1) / 2; continue; }
-                return rc;
+        // A task is one wave's serial work, so no task may be a large part of the whole launch (TRUST-I, one wavelength,
+        // 85 801 cells: a first-level cell costs 1 s of wave time in a 0.7 s launch, and with 8 ranks the launch is 0.09 s).
+        // From the wave cycles every source took in the previous cell-source launch (DRT_A_SRC_COST; sources without one
+        // count as average; no costs, no cutting), with limit = ideal launch time / DRT_HEAVY_DIV (default 16, 0 = off):
+        //  * heavy sources - a task of Gtry sectors would exceed the limit - get fewer sectors per task, down to one; their
+        //    tasks are listed explicitly (StageArgs::heavy) and go first, heaviest source first;
+        //  * deep sources - even one sector (1/48 of the cost on average; the sectors in the plane of a slab cost several
+        //    times that) would exceed it - are run as sub-tree tasks like the point sources, before the others.
+        double heavy_div = 16.0;
+        if (const char* e = getenv("DRT_HEAVY_DIV")) heavy_div = atof(e);
+        std::vector<int> light, deep;
+        std::vector<int2> heavy;
+        auto plan = [&](int Gbase) {
+            light.clear(); heavy.clear(); deep.clear();
+            size_t known = 0;
+            double csum = 0;
+            for (int i : list) if (c->src_cost_h[(size_t)i] > 0) { known++; csum += c->src_cost_h[(size_t)i]; }
+            if (!(heavy_div > 0) || known * 2 <= list.size()) { light = list; return; }
+            const double mean = csum / (double)known;
+            const double total = csum + mean * (double)(list.size() - known);
+            const double limit = total / (double)c->waves / heavy_div;
+            std::vector<std::pair<double, int>> hv;
+            for (int i : list) {
+                const double v = c->src_cost_h[(size_t)i] > 0 ? c->src_cost_h[(size_t)i] : mean;
+                if (v / 48.0 > limit) deep.push_back(i);
+                else if (v * Gbase / 48.0 > limit) hv.push_back({v, i});
+                else light.push_back(i);
             }
+            std::stable_sort(hv.begin(), hv.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+            for (auto& h : hv) {
+                int Gi = Gbase;
+                while (Gi > 1 && h.first * Gi / 48.0 > limit) Gi >>= 1;
+                for (int s0 = 0; s0 < 48; s0 += Gi) heavy.push_back(make_int2(h.second, s0 | (Gi << 8)));
+            }
+        };
+        for (;;) {
+            plan(Gtry);
+            if (heavy.size() > c->heavy_cap || !c->d_heavy) {
+                if (c->d_heavy) (void)hipFree(c->d_heavy);
+                c->heavy_cap = heavy.size() + 4096;
+                HIPCHK(c, hipMalloc((void**)&c->d_heavy, c->heavy_cap * sizeof(int2)));
+            }
+            if (deep.size() > c->deep_cap || !c->d_deep) {
+                if (c->d_deep) (void)hipFree(c->d_deep);
+                c->deep_cap = deep.size() + 1024;
+                HIPCHK(c, hipMalloc((void**)&c->d_deep, c->deep_cap * sizeof(int)));
+            }
+            if (!heavy.empty()) HIPCHK(c, hipMemcpy(c->d_heavy, heavy.data(), heavy.size() * sizeof(int2), hipMemcpyHostToDevice));
+            if (!deep.empty()) HIPCHK(c, hipMemcpy(c->d_deep, deep.data(), deep.size() * sizeof(int), hipMemcpyHostToDevice));
+            if (!light.empty()) HIPCHK(c, hipMemcpy(c->d_src_list, light.data(), light.size() * sizeof(int), hipMemcpyHostToDevice));
             if ((rc = copy_state(true))) return rc;
-            HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+            HIPCHK(c, hipMemsetAsync(c->d_src_cost, 0, (size_t)c->N * sizeof(double), 0));
             HIPCHK(c, hipEventRecord(c->ev0, 0));
-            launch(blocks);
-            c->cnt.launches++;
-            bool ovf = false;
-            if ((rc = overflowed(ovf))) return rc;
+            bool ovf = false, fewer = false;
+            if (!deep.empty()) {
+                if ((rc = subtree(c->d_deep, (int)deep.size(), 0, 1, max_blocks, ovf, fewer))) return rc;
+                if (fewer) { max_blocks = std::max(1, max_blocks / 2); continue; }
+            }
+            if (!ovf && heavy.size() + light.size() > 0) {
+                a.sectors_per_task = Gtry;
+                a.heavy = c->d_heavy; a.n_heavy = (int)heavy.size(); a.nsources = (int)light.size();
+                ntasks = (long long)heavy.size() + (long long)light.size() * (48 / Gtry);
+                blocks = (int)std::max(1ll, std::min((ntasks + 3) / 4, (long long)max_blocks));
+                if ((rc = carve_arena(c, blocks * 4, a))) {  // not even 64-ray queues for this many waves: use fewer
+                    if (rc == DRT_E_CAPACITY && blocks > 1) { if ((rc = copy_state(false))) return rc; max_blocks = (blocks + 1) / 2; continue; }
+                    return rc;
+                }
+                HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
+                launch(blocks);
+                c->cnt.launches++;
+                if ((rc = overflowed(ovf))) return rc;
+            }
             if (!ovf) break;
+            c->overflow_met = true;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
             if (Gtry > 1) Gtry /= 2;                  // shorter queues first,
             else if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;  // then fewer waves with deeper ones
             else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
-        if (c->cnt.launches > 1) c->G_cell = Gtry;  // an overflow was met: more sectors than this do not fit this arena
+        if (c->overflow_met) c->G_cell = c->G_cell > 0 ? std::min(c->G_cell, Gtry) : Gtry;  // an overflow was met: more sectors than this do not fit this arena
+        c->overflow_met = false;
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, 0));
@@ -1232,6 +1355,9 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
             hipLaunchKernelGGL(k_scale_sub, dim3(1), dim3(64), 0, 0, c->d_lum_lost, c->d_lum_lost_prev, (c->par.np_mpi - 1.0) / c->par.np_mpi, c->L);
         if ((rc = allreduce_sum(c, c->d_lum_lost, (size_t)c->L))) return rc;
     } else return fail(c, DRT_E_ARG, "drt_rt_mpi: rt_type %d has no reduction (io_routines.f90:3697)", rt_type);
+    // not in the reference: the wave time per cell source of the stage's cell launch, known to the rank that traced it, for
+    // every rank's next deal (build_src_list)
+    if ((rc = allreduce_sum(c, c->d_src_cost, (size_t)c->N))) return rc;
     HIPCHK(c, hipDeviceSynchronize());
     return DRT_OK;
 }
@@ -1251,6 +1377,7 @@ static int field_ptr(drt_ctx* c, int which, int il, double** d, size_t* n, size_
     case DRT_A_DENS: *d = c->d_dens; *n = NL; break;
     case DRT_A_LUM_LOST: *d = c->d_lum_lost; *n = (size_t)c->L; break;
     case DRT_A_LUM_LOST_PREV: *d = c->d_lum_lost_prev; *n = (size_t)c->L; break;
+    case DRT_A_SRC_COST: *d = c->d_src_cost; *n = (size_t)c->N; break;
     case DRT_A_I_OBS: *d = c->d_i_obs; *n = (size_t)c->ndir * (c->N + c->nsrc) * c->L; break;
     case DRT_A_SCASPE: case DRT_A_SCASPE_TOT: case DRT_A_SCASPE_PREV: {
         if (il < 0 || il >= c->L) return fail(c, DRT_E_ARG, "wavelength index %d out of range", il);

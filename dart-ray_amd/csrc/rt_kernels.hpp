@@ -35,6 +35,12 @@ struct StageArgs {
     // Several ranks share the (source, sector) tasks of a point-source stage: this rank runs the tasks
     // task_first + k * task_stride (rt_routines.f90:1356-1358: the 48 sectors of a source are independent)
     int task_first, task_stride;
+    // Cell sources that cost the waves most in the previous launch (DevProblem::src_cost) are cut into smaller tasks, which
+    // come first: heavy[t] = (cell, first sector | sectors << 8) for t < n_heavy; the tasks of the other sources follow,
+    // sectors_per_task sectors each. A task is one wave's serial work: no task may be a large part of the whole launch.
+    const int2* heavy;
+    int n_heavy;
+    int record_cost;    // add every task's duration to DevProblem::src_cost[cell] (cell-source stages)
     // phase-alignment window of the ray-major kernel in cell sizes (0 = every busy ray steps every time), see trace_items_w
     double phase_win;
 };
@@ -1002,7 +1008,7 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
     const int G = a.sectors_per_task;
     const int tasks_per_src = 48 / G;
     const bool from_spawn = a.spawn_count > 0;
-    const int ntasks = from_spawn ? 4 * a.spawn_count : a.nsources * tasks_per_src;
+    const int ntasks = from_spawn ? 4 * a.spawn_count : a.n_heavy + a.nsources * tasks_per_src;
     const ListView SP = list_view(a.spawn, 0, a.spawn_cap, LP, 0);
     const int* spawn_src = (const int*)(a.spawn + list_bytes(a.spawn_cap, LP));
     const int rt = a.rt_type;
@@ -1025,8 +1031,11 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
         if (lane == 0) task = __atomic_load_n(P.error, __ATOMIC_RELAXED) ? 0x7fffffff : a.task_first + a.task_stride * atomicAdd(P.task_counter, 1);  // stop at the first error anywhere
         task = first_lane_i(task);
         if (task >= ntasks) break;
-        const int nc = from_spawn ? spawn_src[task >> 2] : a.src_list[task / tasks_per_src];
-        const int grp_id = task % tasks_per_src;
+        const unsigned long long t_task = __builtin_amdgcn_s_memtime();
+        int nc, sec0 = 0, Gt = G;
+        if (from_spawn) nc = spawn_src[task >> 2];
+        else if (task < a.n_heavy) { const int2 h = a.heavy[task]; nc = h.x; sec0 = h.y & 255; Gt = h.y >> 8; }
+        else { const int t = task - a.n_heavy; nc = a.src_list[t / tasks_per_src]; sec0 = (t % tasks_per_src) * G; }
         SrcInfo S;
         S.nc = nc;
         S.lvl_nc = P.lvl[nc];
@@ -1052,11 +1061,11 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
             if (rt == RTT_PRECALC_SRC || rt == RTT_DIR_SRC) src_lum = P.p_src_lum[(unsigned long long)P.src_cell[nc] * P.L + il];
             else src_lum = P.lumcell[(unsigned long long)nc * P.L + il];
         }
-        int nH = G, nL = 0, level = 4;
+        int nH = Gt, nL = 0, level = 4;
         if (!from_spawn) {
-            for (int s = lane / LP; s < G; s += 64 / LP) {
+            for (int s = lane / LP; s < Gt; s += 64 / LP) {
                 if (il == 0) {
-                    Hc.ipix[s] = (uint32_t)(grp_id * G + s);  // idir*4 + idir2 at nside 2
+                    Hc.ipix[s] = (uint32_t)(sec0 + s);  // idir*4 + idir2 at nside 2
                     Hc.meta[s] = META(1, 0, RAY_HIGH, 0);
                     Hc.cc[s] = nc;
                     Hc.prev[s] = 0.0;
@@ -1130,6 +1139,7 @@ __device__ __forceinline__ void rt_stage_body(const DevProblem* __restrict__ Pp,
             for (int off = LP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
             if (lane < LP && lane < P.L && v != 0.0) atomicAdd(&P.lum_lost[lane], v);
         }
+        if (a.record_cost && lane == 0) atomicAdd(&P.src_cost[nc], (double)(__builtin_amdgcn_s_memtime() - t_task));
         err = wave_or(err);
         if (err) break;
     }

@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     const int G = a.sectors_per_task;
     const int tasks_per_src = 48 / G;
     const bool from_spawn = a.spawn_count > 0;
-    const int ntasks = from_spawn ? 4 * a.spawn_count : a.nsources * tasks_per_src;
+    const int ntasks = from_spawn ? 4 * a.spawn_count : a.n_heavy + a.nsources * tasks_per_src;
     const ListView SP = list_view(a.spawn, 0, a.spawn_cap, LP, 0);
     const int* spawn_src = (const int*)(a.spawn + list_bytes(a.spawn_cap, LP));
     const int rt = a.rt_type;
@@ -716,8 +716,11 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         if (lane == 0) task = __atomic_load_n(P.error, __ATOMIC_RELAXED) ? 0x7fffffff : a.task_first + a.task_stride * atomicAdd(P.task_counter, 1);  // stop at the first error anywhere
         task = first_lane_i(task);
         if (task >= ntasks) break;
-        const int nc = from_spawn ? spawn_src[task >> 2] : a.src_list[task / tasks_per_src];
-        const int grp_id = task % tasks_per_src;
+        const unsigned long long t_task = __builtin_amdgcn_s_memtime();
+        int nc, sec0 = 0, Gt = G;
+        if (from_spawn) nc = spawn_src[task >> 2];
+        else if (task < a.n_heavy) { const int2 h = a.heavy[task]; nc = h.x; sec0 = h.y & 255; Gt = h.y >> 8; }
+        else { const int t = task - a.n_heavy; nc = a.src_list[t / tasks_per_src]; sec0 = (t % tasks_per_src) * G; }
         SrcInfo S;
         S.nc = nc;
         S.lvl_nc = P.lvl[nc];
@@ -739,10 +742,10 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         ListView Hn = list_view(abase, lbytes, a.cap, LP, 1);
         const ListView LW = list_view(abase, lbytes, a.cap, LP, 2);
         const ListView ST = list_view(abase, lbytes, a.cap, LP, 3);
-        int nH = G, nL = 0, level = 4;
+        int nH = Gt, nL = 0, level = 4;
         if (!from_spawn) {
-            if (lane < G) {
-                Hc.ipix[lane] = (uint32_t)(grp_id * G + lane);  // idir*4 + idir2 at nside 2
+            if (lane < Gt) {
+                Hc.ipix[lane] = (uint32_t)(sec0 + lane);  // idir*4 + idir2 at nside 2
                 Hc.meta[lane] = META(1, 0, RAY_HIGH, 0);
                 Hc.cc[lane] = nc;
                 Hc.prev[lane] = 0.0;
@@ -822,6 +825,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
             }
             wave_fence();
         }
+        if (a.record_cost && lane == 0) atomicAdd(&P.src_cost[nc], (double)(__builtin_amdgcn_s_memtime() - t_task));
         err = wave_or(err);
         if (err) break;
     }

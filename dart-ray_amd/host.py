@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("DRT_LIB", os.path.join(CSRC, "libdartray_rt.so"))
 
 RTT = dict(start=0, precalc_cell=1, precalc_src=2, prep_part2=4, dir_cell=5, i_obs_dir_cell=6, dir_src=7,
            i_obs_dir_src=8, scatt=10, i_obs=11)
-A = dict(u_fest=1, u_final=2, scaspe=3, scaspe_tot=4, scaspe_prev=5, lumcell=6, lum_lost=7, i_obs=8, dens=9,
+A = dict(src_cost=13, u_fest=1, u_final=2, scaspe=3, scaspe_tot=4, scaspe_prev=5, lumcell=6, lum_lost=7, i_obs=8, dens=9,
          dens_stars=10, tot_rad_en=11, lum_lost_prev=12)
 UNIQUE_ID_BYTES = 128
 
@@ -209,7 +209,8 @@ class DartRayGPU:
     def mpi_fields(self, rt):
         """The device buffers rt_mpi reduces for this stage, as zero-copy torch tensors."""
         rt = RTT[rt] if isinstance(rt, str) else rt
-        fields = {"u_fest": self.device_tensor("u_fest"), "u_final": self.device_tensor("u_final")}
+        fields = {"u_fest": self.device_tensor("u_fest"), "u_final": self.device_tensor("u_final"),
+                  "src_cost": self.device_tensor("src_cost")}
         if rt != RTT["precalc_src"]:
             fields["lum_lost"] = self.device_tensor("lum_lost")
             fields["lum_lost_prev"] = self.device_tensor("lum_lost_prev")
@@ -259,7 +260,7 @@ class DartRayGPU:
     def _count(self, which, il):
         NL = self.N * self.L
         return {"u_fest": NL, "u_final": NL, "lumcell": NL, "dens": NL, "dens_stars": NL, "lum_lost": self.L,
-                "tot_rad_en": self.L, "lum_lost_prev": self.L, "i_obs": self.ndir * (self.N + self.nsrc) * self.L,
+                "tot_rad_en": self.L, "lum_lost_prev": self.L, "src_cost": self.N, "i_obs": self.ndir * (self.N + self.nsrc) * self.L,
                 "scaspe": None, "scaspe_tot": None, "scaspe_prev": None}[which]
 
     def get_array(self, which: str, il: int = 0) -> np.ndarray:

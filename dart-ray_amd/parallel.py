@@ -43,6 +43,10 @@ def _steps(rt_type: int, f: Dict[str, object], npr: int):
         steps.append((f["lum_lost"], None))
     else:
         raise ValueError(f"rt_mpi: rt_type {rt_type} has no reduction (io_routines.f90:3697)")
+    # not in the reference: the measured wave time per cell source (DRT_A_SRC_COST), known to the rank that traced it, is
+    # what every rank deals the next stage's sources by
+    if f.get("src_cost") is not None:
+        steps.append((f["src_cost"], None))
     return steps
 
 

@@ -58,6 +58,9 @@ extern "C" {
 #define DRT_A_DENS_STARS 10 /* dens_stars_arr                                :70  */
 #define DRT_A_TOT_RAD_EN 11 /* tot_rad_en(0:lnum-1)           rt_routines.f90:33  */
 #define DRT_A_LUM_LOST_PREV 12 /* lum_lost_prev(0:lnum-1)     rt_routines.f90:133 */
+#define DRT_A_SRC_COST 13  /* [tot_ncell] no reference counterpart: wave cycles spent on each cell source in the last cell-source
+                            * rt_loop (zero elsewhere). Steers the task order / rank shares of the next one; with np_mpi > 1 it
+                            * is summed over the ranks in rt_mpi like the fields (every source is traced by exactly one rank). */
 
 typedef struct drt_ctx drt_ctx;
 

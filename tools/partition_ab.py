@@ -24,15 +24,24 @@ g.L_.drt_debug_set_rank.argtypes = [C.c_void_p, C.c_int, C.c_int]
 g.rt_loop("scatt")  # warm-up: settles the sectors per task
 full = g.counters()
 print(f"N={case.tree.ncell} L={case.lnum} one rank: {full['kernel_ms']:.1f} ms, {full['intersections']:.3e} intersections", flush=True)
-for part in ("cyclic64", "cyclic256", "cyclic1024", "block", "mod"):
+full_cost = g.get_array("src_cost")  # what rt_mpi would hand every rank: the cost of every source in the previous launch
+for part, heavy in (("cyclic64", "0"), ("cyclic64", "16"), ("cost", "16"), ("cost", "32"), ("block", "16"), ("mod", "16")):
     os.environ["DRT_PARTITION"] = part[:6] if part.startswith("cyclic") else part
+    os.environ["DRT_HEAVY_DIV"] = heavy
     if part.startswith("cyclic"):
         os.environ["DRT_PARTITION_CHUNK"] = part[6:]
     ms, inter = [], []
     for r in range(npr):
         g.L_.drt_debug_set_rank(g.h, npr, r)
+        g.set_array("src_cost", full_cost)
         g.reset_counters(); g.rt_loop("scatt"); c = g.counters()
         ms.append(c["kernel_ms"]); inter.append(c["intersections"])
-    print(f"{part:10s} np={npr}: per-rank ms {[round(x, 1) for x in ms]} max {max(ms):.1f} sum {sum(ms):.1f} "
+    print(f"{part:10s} heavy_div={heavy:3s} np={npr}: per-rank ms {[round(x, 1) for x in ms]} max {max(ms):.1f} sum {sum(ms):.1f} "
           f"| intersections max/mean {max(inter) / (sum(inter) / npr):.3f} | speed-up over one rank {full['kernel_ms'] / max(ms):.2f}", flush=True)
 g.L_.drt_debug_set_rank(g.h, 1, 0)
+os.environ.pop("DRT_PARTITION", None)
+for heavy in ("0", "8", "16", "32"):
+    os.environ["DRT_HEAVY_DIV"] = heavy
+    g.set_array("src_cost", full_cost)
+    g.reset_counters(); g.rt_loop("scatt"); c = g.counters()
+    print(f"one rank, heavy_div={heavy}: {c['kernel_ms']:.1f} ms", flush=True)
