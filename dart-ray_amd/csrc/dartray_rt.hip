@@ -975,7 +975,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if ((rc = build_src_list(c, rt_type, list))) return rc;
     const int64_t inter_before = c->cnt.intersections;  // the device counters run on until drt_reset_counters
     c->cnt.sources = (int64_t)list.size();
-    c->cnt.kernel_ms = 0; c->cnt.launches = 0;
+    c->cnt.kernel_ms = 0; c->cnt.launches = 0; c->cnt.heavy_tasks = 0; c->cnt.deep_sources = 0;
     const bool cell_stage = !(rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC);
     if (cell_stage) HIPCHK(c, hipMemset(c->d_src_cost, 0, (size_t)c->N * sizeof(double)));  // build_src_list has read the previous launch's
     if (list.empty()) return DRT_OK;
@@ -1182,6 +1182,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (!heavy.empty()) HIPCHK(c, hipMemcpy(c->d_heavy, heavy.data(), heavy.size() * sizeof(int2), hipMemcpyHostToDevice));
             if (!deep.empty()) HIPCHK(c, hipMemcpy(c->d_deep, deep.data(), deep.size() * sizeof(int), hipMemcpyHostToDevice));
             if (!light.empty()) HIPCHK(c, hipMemcpy(c->d_src_list, light.data(), light.size() * sizeof(int), hipMemcpyHostToDevice));
+            c->cnt.heavy_tasks = (int64_t)heavy.size(); c->cnt.deep_sources = (int64_t)deep.size();
             if ((rc = copy_state(true))) return rc;
             HIPCHK(c, hipMemsetAsync(c->d_src_cost, 0, (size_t)c->N * sizeof(double), 0));
             HIPCHK(c, hipEventRecord(c->ev0, 0));

@@ -39,7 +39,8 @@ class Counters(C.Structure):
     _fields_ = [("intersections", C.c_int64), ("rays", C.c_int64), ("deposits", C.c_int64), ("scaspe_adds", C.c_int64),
                 ("lambda_deposits", C.c_int64), ("u_adds", C.c_int64), ("u_reads", C.c_int64), ("scaspe_slots", C.c_int64),
                 ("sources", C.c_int64), ("kernel_ms", C.c_double), ("launches", C.c_int64),
-                ("atomic_instructions", C.c_int64), ("atomic_lanes", C.c_int64)]
+                ("atomic_instructions", C.c_int64), ("atomic_lanes", C.c_int64),
+                ("heavy_tasks", C.c_int64), ("deep_sources", C.c_int64)]
 
 
 EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_set_grid", "drt_set_params",

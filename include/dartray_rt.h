@@ -96,6 +96,8 @@ typedef struct drt_counters {
     int64_t launches;      /* kernel launches behind kernel_ms */
     int64_t atomic_instructions; /* f64 atomic wave-instructions issued for scaspe / u_final by the deposit loop */
     int64_t atomic_lanes;  /* active lanes summed over those instructions (8 bytes of payload each) */
+    int64_t heavy_tasks;   /* last rt_loop: tasks of cell sources cut into fewer sectors per task (measured-cost scheduling) */
+    int64_t deep_sources;  /* last rt_loop: cell sources run as sub-tree tasks */
 } drt_counters;
 
 /* ---- life cycle ------------------------------------------------------------------------------- */

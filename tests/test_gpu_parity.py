@@ -126,6 +126,50 @@ def test_queue_overflow_is_undone_and_retried(name, golden, pkg):
     g.close()
 
 
+def test_measured_cost_scheduling_changes_the_tasks_not_the_result(golden, pkg, monkeypatch):
+    """From the second cell-source launch on, the wave time every source took in the previous one (DRT_A_SRC_COST) cuts the
+    expensive sources into smaller tasks (fewer sectors per task, listed in front) or runs them as sub-tree tasks like
+    point sources. The sectors of a source are independent (rt_routines.f90:1356-1358) and the ladders below distinct
+    nside-8 pixels never exchange rays (:2494), so the rays, intersections and deposits must stay EXACTLY those of the
+    reference whatever the cut, and the fields within the usual tolerance. On this small grid the default limit
+    (DRT_HEAVY_DIV = 16) already gives a mix of deep and heavy sources, a very fine one makes every source deep (the
+    whole scattering stage then runs through sub-tree tasks), 0 switches the cutting off."""
+    z, path = golden("trusti32")
+    case = pkg.grids.read_case(path, "trusti32")
+    seen = {}
+    for div in ("16", "100000", "0"):
+        monkeypatch.setenv("DRT_HEAVY_DIV", div)
+        g = pkg.DartRayGPU(case)
+        used = []
+        g.rt_prepare("start")
+        g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+        g.rt_prepare("prep_part2")
+        g.rt_loop("dir_cell"); g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+        while not g.scatt_prepare():
+            g.rt_loop("scatt")
+            c = g.counters()
+            used.append((int(c["heavy_tasks"]), int(c["deep_sources"]), int(c["sources"])))
+            cost = g.get_array("src_cost")
+            assert int((cost > 0).sum()) == int(c["sources"])     # every source of the launch has a measured cost
+            g.rt_mpi("scatt")
+        assert g.iterations == int(z["iterations"])
+        c = g.counters()
+        seen[div] = (int(c["rays"]), int(c["intersections"]), int(c["deposits"]))
+        assert relmax(g.u_final, z["u_final"]) <= RTOL and relelem(g.u_final, z["u_final"]) <= RTOL_ELEM
+        assert relmax(g.lum_lost, z["lum_lost"]) <= 1e-7
+        for il in range(0, g.L, 5):
+            golden_scaspe_check(z, "scaspe_tot", il, g.scaspe_tot(il), RTOL, "trusti32", RTOL_ELEM)
+        assert used[0][:2] == (0, 0)                               # first launch of the stage kind: no costs yet
+        if div == "100000":
+            assert all(u[1] == u[2] for u in used[1:]), used      # all deep
+        elif div == "0":
+            assert all(u[:2] == (0, 0) for u in used), used
+        else:
+            assert any(0 < u[1] < u[2] and u[0] > 0 for u in used[1:]), used   # a mix
+        g.close()
+    assert seen["16"] == seen["0"] == seen["100000"], seen
+
+
 def test_point_source_overflow_is_a_clean_capacity_error(golden, pkg, monkeypatch):
     """Sub-tree tasks of a point source with 4-ray queues (DRT_TEST_MAX_CAP, a test aid of carve_arena; with the 64 rays
     of the smallest real arena the sub-tree ladders of the test cases never overflow): the
