@@ -100,7 +100,11 @@ struct drt_ctx {
     double *d_ccoord = nullptr, *d_csize = nullptr, *d_dens = nullptr, *d_u_fest = nullptr, *d_u_final = nullptr, *d_lumcell = nullptr;
     double *d_p_src_pos = nullptr, *d_p_src_lum = nullptr, *d_dir_out = nullptr, *d_lum_lost = nullptr, *d_lum_lost_prev = nullptr;
     double *d_i_obs = nullptr, *d_tot = nullptr, *d_src_cost = nullptr;
-    std::vector<double> src_cost_h;  // d_src_cost as build_src_list last read it
+    // Measured-cost scheduling (build_src_list): src_pred_h[i] = the wave time cell source i is expected to take in the launch
+    // being prepared; cost_lum_h[i] = its luminosity (sum over the wavelengths) in the launch d_src_cost was measured in,
+    // cost_kind = that launch's rt_type (-1: nothing measured yet)
+    std::vector<double> src_pred_h, cost_lum_h;
+    int cost_kind = -1;
     std::vector<double*> d_scaspe, d_scaspe_prev, d_scaspe_tot, d_tab;
     DevProblem* d_prob = nullptr;
     DevProblem hprob{};
@@ -843,7 +847,7 @@ extern "C" int drt_rt_prepare(drt_ctx* c, int32_t rt_type)
 //  * chunks keep neighbours together (a GPU has ~170 sources in flight at once) and sample the whole model.
 // Point sources are not shared here: every rank takes all of them and the ranks split their (source, sector) tasks
 // instead (StageArgs::task_first/task_stride). rt_loop_iobs runs on the main rank only (rt_routines.f90:1483, :1498).
-static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list)
+static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool launching = false)
 {
     const int N = c->N, L = c->L, np = c->par.np_mpi, id = c->par.id_mpi;
     list.clear();
@@ -863,29 +867,53 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list)
         list.push_back(i);
     }
     // the wave time every source took in the previous cell-source launch, summed over the ranks by rt_mpi
+    // Expected cost of every source of this launch. Measured (same kind of stage, cost known): the measured wave time times
+    // the ratio of the source's luminosity now and then - a source emits fewer rays as its luminosity falls from one
+    // scattering iteration to the next (bench grid: the time of a source falls to 8-34 % from iteration 1 to 2, exponent 1
+    // predicts the ranks' shares to 4-19 %; unchanged luminosity, as in a repeated step: the measurement itself).
+    // Otherwise a prior, sqrt(luminosity), scaled to the measured ones if there are any: log cost against log luminosity
+    // is a line of slope 0.5-0.9 with correlation 0.91-0.98 on the bench grid. Only ratios of these numbers are used.
     if (!iobs && !psrc && c->d_src_cost) {
-        c->src_cost_h.resize((size_t)N);
-        HIPCHK(c, hipMemcpy(c->src_cost_h.data(), c->d_src_cost, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> meas((size_t)N);
+        HIPCHK(c, hipMemcpy(meas.data(), c->d_src_cost, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+        c->src_pred_h.assign((size_t)N, 0.0);
+        if (c->cost_lum_h.size() != (size_t)N) c->cost_lum_h.assign((size_t)N, 0.0);
+        const bool same_kind = (c->cost_kind == rt_type);
+        double sum_meas = 0, sum_prior = 0;
+        std::vector<double> lum(list.size());
+        for (size_t k = 0; k < list.size(); k++) {
+            const size_t i = (size_t)list[k];
+            double s = 0;
+            for (int il = 0; il < L; il++) s += c->lumcell_h[i * L + il];
+            lum[k] = s;
+            if (same_kind && meas[i] > 0 && c->cost_lum_h[i] > 0) { sum_meas += meas[i]; sum_prior += sqrt(c->cost_lum_h[i]); }
+        }
+        const double scale = sum_prior > 0 ? sum_meas / sum_prior : 1.0;
+        for (size_t k = 0; k < list.size(); k++) {
+            const size_t i = (size_t)list[k];
+            if (same_kind && meas[i] > 0 && c->cost_lum_h[i] > 0) c->src_pred_h[i] = meas[i] * (lum[k] / c->cost_lum_h[i]);
+            else c->src_pred_h[i] = scale * sqrt(lum[k]);
+            if (launching) c->cost_lum_h[i] = lum[k];  // the launch being prepared is the next one measured
+        }
+        if (launching) c->cost_kind = rt_type;
     }
     if (!iobs && !psrc && !by_mod && np > 1) {
         const size_t n = list.size();
         std::vector<int> mine;
-        size_t known = 0;
         double csum = 0;
-        for (int i : list) if (c->src_cost_h[(size_t)i] > 0) { known++; csum += c->src_cost_h[(size_t)i]; }
-        const bool by_cost = !by_block && !(pe && !strcmp(pe, "cyclic")) && known * 2 > n;
+        for (int i : list) csum += c->src_pred_h[(size_t)i];
+        const bool by_cost = !by_block && !(pe && !strcmp(pe, "cyclic")) && csum > 0;
         if (by_cost) {
-            // Longest-processing-time deal of chunks of consecutive sources, by measured cost: the chunks keep neighbours
+            // Longest-processing-time deal of chunks of consecutive sources, by expected cost: the chunks keep neighbours
             // together, a source that costs more than 1/64 of a rank's share is a chunk of its own; heaviest chunk first to
             // the least loaded rank (ties: lower rank). Every rank computes the same deal from the same (all-reduced) costs.
-            const double mean = csum / (double)known, big = csum / np / 64.0;
+            const double big = csum / np / 64.0;
             struct Chunk { size_t lo, hi; double cost; };
             std::vector<Chunk> ch;
             for (size_t k = 0; k < n;) {
                 Chunk q{k, k, 0.0};
                 while (q.hi < n && q.hi - q.lo < chunk) {
-                    double v = c->src_cost_h[(size_t)list[q.hi]];
-                    if (!(v > 0)) v = mean;
+                    const double v = c->src_pred_h[(size_t)list[q.hi]];
                     if (v > big) { if (q.hi == q.lo) { q.cost = v; q.hi++; } break; }
                     q.cost += v; q.hi++;
                 }
@@ -972,7 +1000,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     std::vector<int> list;
-    if ((rc = build_src_list(c, rt_type, list))) return rc;
+    if ((rc = build_src_list(c, rt_type, list, true))) return rc;
     const int64_t inter_before = c->cnt.intersections;  // the device counters run on until drt_reset_counters
     c->cnt.sources = (int64_t)list.size();
     c->cnt.kernel_ms = 0; c->cnt.launches = 0; c->cnt.heavy_tasks = 0; c->cnt.deep_sources = 0;
@@ -1134,8 +1162,9 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         int max_blocks = c->waves / 4;
         // A task is one wave's serial work, so no task may be a large part of the whole launch (TRUST-I, one wavelength,
         // 85 801 cells: a first-level cell costs 1 s of wave time in a 0.7 s launch, and with 8 ranks the launch is 0.09 s).
-        // From the wave cycles every source took in the previous cell-source launch (DRT_A_SRC_COST; sources without one
-        // count as average; no costs, no cutting), with limit = ideal launch time / DRT_HEAVY_DIV (default 16, 0 = off):
+        // From the expected cost of every source (src_pred_h: the wave cycles it took in the previous launch of this kind of
+        // stage, DRT_A_SRC_COST, scaled with its luminosity; sqrt(luminosity) for a first launch), with
+        // limit = ideal launch time / DRT_HEAVY_DIV (default 16, 0 = off):
         //  * heavy sources - a task of Gtry sectors would exceed the limit - get fewer sectors per task, down to one; their
         //    tasks are listed explicitly (StageArgs::heavy) and go first, heaviest source first;
         //  * deep sources - even one sector (1/48 of the cost on average; the sectors in the plane of a slab cost several
@@ -1146,16 +1175,13 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         std::vector<int2> heavy;
         auto plan = [&](int Gbase) {
             light.clear(); heavy.clear(); deep.clear();
-            size_t known = 0;
-            double csum = 0;
-            for (int i : list) if (c->src_cost_h[(size_t)i] > 0) { known++; csum += c->src_cost_h[(size_t)i]; }
-            if (!(heavy_div > 0) || known * 2 <= list.size()) { light = list; return; }
-            const double mean = csum / (double)known;
-            const double total = csum + mean * (double)(list.size() - known);
+            double total = 0;
+            for (int i : list) total += c->src_pred_h[(size_t)i];
+            if (!(heavy_div > 0) || !(total > 0)) { light = list; return; }
             const double limit = total / (double)c->waves / heavy_div;
             std::vector<std::pair<double, int>> hv;
             for (int i : list) {
-                const double v = c->src_cost_h[(size_t)i] > 0 ? c->src_cost_h[(size_t)i] : mean;
+                const double v = c->src_pred_h[(size_t)i];
                 if (v / 48.0 > limit) deep.push_back(i);
                 else if (v * Gbase / 48.0 > limit) hv.push_back({v, i});
                 else light.push_back(i);
