@@ -105,6 +105,7 @@ struct drt_ctx {
     // cost_kind = that launch's rt_type (-1: nothing measured yet)
     std::vector<double> src_pred_h, cost_lum_h;
     int cost_kind = -1;
+    bool cost_synced = false;  // np_mpi > 1: d_src_cost has been summed over the ranks since the launch that measured it
     std::vector<double*> d_scaspe, d_scaspe_prev, d_scaspe_tot, d_tab;
     DevProblem* d_prob = nullptr;
     DevProblem hprob{};
@@ -889,13 +890,17 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool 
             if (same_kind && meas[i] > 0 && c->cost_lum_h[i] > 0) { sum_meas += meas[i]; sum_prior += sqrt(c->cost_lum_h[i]); }
         }
         const double scale = sum_prior > 0 ? sum_meas / sum_prior : 1.0;
+        // The deal among the ranks must come out the same on every rank: measured costs enter it only once they have been
+        // summed over the ranks (drt_rt_mpi, or the host's own reduction followed by drt_mark_cost_reduced); until then a
+        // rank knows the costs of its own sources only and the deal uses the prior, a function of lumcell, alone.
+        const bool use_meas = same_kind && (np == 1 || c->cost_synced);
         for (size_t k = 0; k < list.size(); k++) {
             const size_t i = (size_t)list[k];
-            if (same_kind && meas[i] > 0 && c->cost_lum_h[i] > 0) c->src_pred_h[i] = meas[i] * (lum[k] / c->cost_lum_h[i]);
-            else c->src_pred_h[i] = scale * sqrt(lum[k]);
+            if (use_meas && meas[i] > 0 && c->cost_lum_h[i] > 0) c->src_pred_h[i] = meas[i] * (lum[k] / c->cost_lum_h[i]);
+            else c->src_pred_h[i] = (use_meas ? scale : 1.0) * sqrt(lum[k]);
             if (launching) c->cost_lum_h[i] = lum[k];  // the launch being prepared is the next one measured
         }
-        if (launching) c->cost_kind = rt_type;
+        if (launching) { c->cost_kind = rt_type; c->cost_synced = false; }
     }
     if (!iobs && !psrc && !by_mod && np > 1) {
         const size_t n = list.size();
@@ -1385,7 +1390,15 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
     // not in the reference: the wave time per cell source of the stage's cell launch, known to the rank that traced it, for
     // every rank's next deal (build_src_list)
     if ((rc = allreduce_sum(c, c->d_src_cost, (size_t)c->N))) return rc;
+    c->cost_synced = true;
     HIPCHK(c, hipDeviceSynchronize());
+    return DRT_OK;
+}
+
+extern "C" int drt_mark_cost_reduced(drt_ctx* c)
+{
+    if (!c) return DRT_E_ARG;
+    c->cost_synced = true;
     return DRT_OK;
 }
 

@@ -156,6 +156,10 @@ module dartray_c
        integer(c_int32_t), intent(out) :: cells(*), count
      end function drt_get_sources
      ! multi-GPU: one rank per GPU, rt_mpi's MPI_Allreduce becomes ncclAllReduce (RCCL over xGMI) on the device buffers
+     integer(c_int) function drt_mark_cost_reduced(ctx) bind(C, name='drt_mark_cost_reduced')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function drt_mark_cost_reduced
      integer(c_int) function drt_comm_unique_id(id) bind(C, name='drt_comm_unique_id')
        import :: c_int, c_char
        character(kind=c_char), intent(out) :: id(128)

@@ -47,7 +47,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced"]
 
 
 def build(force: bool = False) -> str:
@@ -100,6 +100,8 @@ def lib():
         if hasattr(L, "drt_get_sources"):  # absent from libraries of older revisions (A/B runs through DRT_LIB)
             L.drt_get_sources.argtypes = [vp, i32, ip, i32, ip]
             L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        if hasattr(L, "drt_mark_cost_reduced"):
+            L.drt_mark_cost_reduced.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -211,12 +213,16 @@ class DartRayGPU:
         """The device buffers rt_mpi reduces for this stage, as zero-copy torch tensors."""
         rt = RTT[rt] if isinstance(rt, str) else rt
         fields = {"u_fest": self.device_tensor("u_fest"), "u_final": self.device_tensor("u_final"),
-                  "src_cost": self.device_tensor("src_cost")}
+                  "src_cost": self.device_tensor("src_cost"), "src_cost_done": self.mark_cost_reduced}
         if rt != RTT["precalc_src"]:
             fields["lum_lost"] = self.device_tensor("lum_lost")
             fields["lum_lost_prev"] = self.device_tensor("lum_lost_prev")
             fields["scaspe"] = [self.device_tensor("scaspe", il) for il in range(self.L)]
         return fields
+
+    def mark_cost_reduced(self):
+        """DRT_A_SRC_COST has been summed over the ranks (drt_mark_cost_reduced)."""
+        self._chk(self.L_.drt_mark_cost_reduced(self.h))
 
     def attach_process_group(self, group=None):
         """Use an initialised torch.distributed group (backend nccl = RCCL) for the stage-end reductions."""

@@ -46,7 +46,7 @@ def _steps(rt_type: int, f: Dict[str, object], npr: int):
     # not in the reference: the measured wave time per cell source (DRT_A_SRC_COST), known to the rank that traced it, is
     # what every rank deals the next stage's sources by
     if f.get("src_cost") is not None:
-        steps.append((f["src_cost"], None))
+        steps.append((f["src_cost"], f.get("src_cost_done")))
     return steps
 
 

@@ -134,6 +134,10 @@ int drt_rt_loop_iobs(drt_ctx *ctx, int32_t rt_type);
 /* rt_mpi (io_routines.f90:3667): stage-end reductions for rt_type in {2,7,10}; all-reduce over the
  * communicator attached with drt_comm_init (identity + the u_final clamp on one rank) */
 int drt_rt_mpi(drt_ctx *ctx, int32_t rt_type);
+/* For a host that performs rt_mpi's reductions itself on the device buffers (drt_device_ptr): after it has also summed
+ * DRT_A_SRC_COST over the ranks it says so here, and the next cell-source stage deals its sources among the ranks by
+ * those costs. Without the call the deal uses a function of lumcell alone (identical on all ranks by construction). */
+int drt_mark_cost_reduced(drt_ctx *ctx);
 
 /* ---- module state out -------------------------------------------------------------------------------- */
 /* Copy a field to/from the host. il selects the wavelength for the scaspe arrays (ignored

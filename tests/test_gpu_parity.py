@@ -248,7 +248,7 @@ def test_gpu_counters_match_oracle(name, golden, pkg):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("name,partition", [("blobB", "block"), ("blobD", "mod"), ("trusti32", "cyclic"), ("trusti32", "cost"), ("blobE", "cost")])
+@pytest.mark.parametrize("name,partition", [("blobB", "block"), ("blobD", "mod"), ("trusti32", "cyclic"), ("trusti32", "cost"), ("blobE", "cost"), ("trusti32", "cost-unsynced")])
 def test_two_ranks_in_one_process_match_golden(name, partition, golden, pkg, monkeypatch):
     """The product's multi-rank path on ONE GPU: two library contexts (np_mpi = 2, id_mpi = 0 / 1) run every stage on
     their share of the work - cell sources partitioned by build_src_list (chunks of consecutive cells dealt by expected
@@ -271,7 +271,11 @@ def test_two_ranks_in_one_process_match_golden(name, partition, golden, pkg, mon
 
     def mpi(rt):
         torch.cuda.synchronize()
-        parallel.rt_mpi_local(pkg.host.RTT[rt], [g.mpi_fields(rt) for g in ranks])
+        fields = [g.mpi_fields(rt) for g in ranks]
+        if partition == "cost-unsynced":   # a host that reduces the fields itself and knows nothing of DRT_A_SRC_COST: every
+            for f in fields:               # rank keeps the costs of its own sources only, the deal must not use them
+                f.pop("src_cost"); f.pop("src_cost_done")
+        parallel.rt_mpi_local(pkg.host.RTT[rt], fields)
         torch.cuda.synchronize()
 
     def check_partition(rt):
@@ -307,6 +311,10 @@ def test_two_ranks_in_one_process_match_golden(name, partition, golden, pkg, mon
         assert cn[0] == cn[1]
         if cn[0]:
             break
+        # whatever the deal is made from (expected costs from the second iteration on), it is a partition of the emitting leaves
+        parts = [g.sources("scatt") for g in ranks]
+        emitting = np.flatnonzero((ranks[0].get_array("lumcell").sum(axis=1) > 0) & (case.tree.cchild == -1))
+        assert sorted(np.concatenate(parts)) == sorted(emitting) and len(set(parts[0]) & set(parts[1])) == 0
         for g in ranks:
             g.rt_loop("scatt")
         mpi("scatt")
