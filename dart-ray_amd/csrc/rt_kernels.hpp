@@ -151,13 +151,20 @@ __device__ __forceinline__ void gatomic_add(double* p, double v)
 #endif
 }
 
-struct WaveCounters { unsigned long long inter, rays, deps, sca, lamdep, uadd, uread, slots;
+template <class T> struct WaveCountersT { T inter, rays, deps, sca, lamdep, uadd, uread, slots;
     unsigned long long atom, atom_lanes;  // wave-uniform: atomic wave-instructions of the deposit loop and their active lanes
 #ifdef DRT_PROFILE
     unsigned long long t_setup, t_step, t_flush, t_park, t_next, t_commit, t_extract, t_total, n_steps, n_busy_lanes, n_groups, n_deps,
         t_dep, t_ghead, t_memb, t_epi, n_lam, n_memb, n_cls0, n_cls1, n_cls2;  // inside the wavelength loop: deposit arithmetic, group head, member loop, epilogue + atomic
 #endif
 };
+typedef WaveCountersT<unsigned long long> WaveCounters;
+// rt_stage_wide: the eight per-lane tallies in 32 bits (8 registers fewer in a kernel that spills), moved to the 64-bit
+// counters in memory at the end of a task once a lane has passed 2^30
+#ifndef DRT_WIDE_CNT_T
+#define DRT_WIDE_CNT_T unsigned
+#endif
+typedef WaveCountersT<DRT_WIDE_CNT_T> WideCounters;
 #ifdef DRT_PROFILE
 #define TSTAMP(v) unsigned long long v = __builtin_amdgcn_s_memtime()
 #define TACC(field, t0, t1) wc.field += (t1) - (t0)

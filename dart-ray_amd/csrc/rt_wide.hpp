@@ -86,7 +86,7 @@ struct LaneTab {  // lane l: constants of wavelength l
 // dens = dens_arr(l, cc) and, for br == 1, u_fest = u_fest_arr(l, cc) are loaded by the caller one wavelength ahead.
 __device__ __forceinline__ void deposit_lambda(const HotP& P, double ksca_l, int rt, const SrcInfo& S, int br, int cc, int l, double length,
                                                double dens, double u_fest, double beam_i, double beam_f, double csize_f, double vol_f,
-                                               double& I, double& u_add, double& en_sca, double& lost, bool& alive, WaveCounters& wc)
+                                               double& I, double& u_add, double& en_sca, double& lost, bool& alive, WideCounters& wc)
 {
     const int nc = S.nc;
     double tau_c = dens * length;
@@ -163,7 +163,7 @@ __device__ __forceinline__ double pow_m1p5_f(double x)
 #define DRT_BST 64  // row length of the broadcast staging area
 template <bool BIG>
 __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long long M, unsigned long long MC, int cc, double U, const ldouble* bst,
-                                             int l, const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc)
+                                             int l, const SlotTabs& T, const HotP& H, const LaneTab& LT, WideCounters& wc)
 {
     const int lane = lane_id();
     const unsigned long long Mall = M;
@@ -276,7 +276,7 @@ template <int LP, bool BIG>
 __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
                               const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
                               int* __restrict__ ostat, int level, iptr_t Ilds, double* __restrict__ thg, ldouble* ll, ldouble* bst, ldouble* opq,
-                              const SlotTabs& T, const HotP& H, const LaneTab& LT, WaveCounters& wc, int& err)
+                              const SlotTabs& T, const HotP& H, const LaneTab& LT, WideCounters& wc, int& err)
 {
     const int lane = lane_id();
     const int L = (LP == 1) ? 1 : H.L;  // one wavelength: the wavelength loops fold away (-4.5 % on the 85 801-cell grid)
@@ -487,7 +487,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 if (length != 0. && status == ST_CONT) {
                     // deposit, the part that does not depend on the wavelength (rt_routines.f90:2362-2557)
                     wc.deps++;
-                    wc.lamdep += (unsigned long long)__popcll(amask);
+                    wc.lamdep += (DRT_WIDE_CNT_T)__popcll(amask);
                     const int npix_beam = 12 * (level * level);
                     beam_i = 4 * P.pi / npix_beam;
                     const int lv = P.lvl[r.cc];
@@ -565,7 +565,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                 if (e != 0.0) {
                                     C = e / ax;
                                     wc.sca++;
-                                    wc.slots += (unsigned long long)__builtin_amdgcn_readlane(LT.np, l);
+                                    wc.slots += (DRT_WIDE_CNT_T)__builtin_amdgcn_readlane(LT.np, l);
                                 }
                             }
                             TSTAMP(td1);
@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     const ListView SP = list_view(a.spawn, 0, a.spawn_cap, LP, 0);
     const int* spawn_src = (const int*)(a.spawn + list_bytes(a.spawn_cap, LP));
     const int rt = a.rt_type;
-    WaveCounters wc = {};
+    WideCounters wc = {};
     int err = 0;
     TSTAMP(tk0);
     HotP H;
@@ -710,6 +710,23 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         if (P.utab[1] && P.utab_np[1] <= 63 && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
     }
     if (lane < LP) ll[lane] = 0.0;
+    // the per-lane tallies: one atomic per wave and counter
+    auto flush_counters = [&]() {
+        unsigned long long c8[8] = {wc.inter, wc.rays, wc.deps, wc.sca, wc.lamdep, wc.uadd, wc.uread, wc.slots};
+        for (int off = 1; off < 64; off <<= 1)
+            for (int q = 0; q < 8; q++) c8[q] += __shfl_xor(c8[q], off, 64);
+        if (lane == 0) {
+            atomicAdd(&P.counters[CNT_INTERSECTIONS], c8[0]);
+            atomicAdd(&P.counters[CNT_RAYS], c8[1]);
+            atomicAdd(&P.counters[CNT_DEPOSITS], c8[2]);
+            atomicAdd(&P.counters[CNT_SCASPE], c8[3]);
+            atomicAdd(&P.counters[CNT_LAMDEP], c8[4]);
+            atomicAdd(&P.counters[CNT_UADD], c8[5]);
+            atomicAdd(&P.counters[CNT_UREAD], c8[6]);
+            atomicAdd(&P.counters[CNT_SCASLOTS], c8[7]);
+        }
+        wc.inter = wc.rays = wc.deps = wc.sca = wc.lamdep = wc.uadd = wc.uread = wc.slots = 0;
+    };
 
     for (;;) {
         int task = 0;
@@ -826,22 +843,12 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
             wave_fence();
         }
         if (a.record_cost && lane == 0) atomicAdd(&P.src_cost[nc], (double)(__builtin_amdgcn_s_memtime() - t_task));
+        if (sizeof(DRT_WIDE_CNT_T) < 8 && __ballot(((wc.inter | wc.lamdep | wc.slots) >> 30) != 0)) flush_counters();
         err = wave_or(err);
         if (err) break;
     }
-    // counters: one atomic per wave
-    unsigned long long c8[8] = {wc.inter, wc.rays, wc.deps, wc.sca, wc.lamdep, wc.uadd, wc.uread, wc.slots};
-    for (int off = 1; off < 64; off <<= 1)
-        for (int q = 0; q < 8; q++) c8[q] += __shfl_xor(c8[q], off, 64);
+    flush_counters();
     if (lane == 0) {
-        atomicAdd(&P.counters[CNT_INTERSECTIONS], c8[0]);
-        atomicAdd(&P.counters[CNT_RAYS], c8[1]);
-        atomicAdd(&P.counters[CNT_DEPOSITS], c8[2]);
-        atomicAdd(&P.counters[CNT_SCASPE], c8[3]);
-        atomicAdd(&P.counters[CNT_LAMDEP], c8[4]);
-        atomicAdd(&P.counters[CNT_UADD], c8[5]);
-        atomicAdd(&P.counters[CNT_UREAD], c8[6]);
-        atomicAdd(&P.counters[CNT_SCASLOTS], c8[7]);
         atomicAdd(&P.counters[CNT_ATOM], wc.atom);
         atomicAdd(&P.counters[CNT_ATOM_LANES], wc.atom_lanes);
 #ifdef DRT_PROFILE
