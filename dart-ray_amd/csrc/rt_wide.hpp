@@ -703,10 +703,13 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     H.skip_atomics = P.dbg_flags & 1;
 #endif
     LaneTab LT = {0.0, 0.0, 0, 0, -1, 0ull};
-    if (lane < P.L) { LT.g = P.g[lane]; LT.ksca = P.ksca[lane]; LT.np = P.npix[lane]; LT.ns = P.nstride[lane]; LT.tid = P.tabid[lane]; LT.srow = (unsigned long long)P.scaspe[lane]; }
+    if constexpr (LP == 1) {  // one wavelength: the row of the table is the same in every lane and lives in scalar registers
+        LT.g = P.g[0]; LT.ksca = P.ksca[0]; LT.np = P.npix[0]; LT.ns = P.nstride[0]; LT.tid = P.tabid[0]; LT.srow = (unsigned long long)P.scaspe[0];
+    } else if (lane < P.L) { LT.g = P.g[lane]; LT.ksca = P.ksca[lane]; LT.np = P.npix[lane]; LT.ns = P.nstride[lane]; LT.tid = P.tabid[lane]; LT.srow = (unsigned long long)P.scaspe[lane]; }
     SlotTabs T = {0, 0, 0, 0, 0, 0};
     if (a.scatter) {
         if (P.utab[0] && P.utab_np[0] <= 63 && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }
+        if constexpr (LP > 1)  // one wavelength has one table
         if (P.utab[1] && P.utab_np[1] <= 63 && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
     }
     if (lane < LP) ll[lane] = 0.0;
