@@ -113,7 +113,10 @@ struct Ray {
     int cc, clvl, clvl_old, cc_new, isel_old, ipix_dir;
     bool flag_beam, lam_active;
     uint32_t cx, cy, cz;
-    int inc0, inc1, inc2;
+    int incs;  // the direction's sign along x, y, z (-1, 0, 1), two bits each (+1): one register instead of three took the
+               // one-wavelength step of rt_stage_wide from 632 to 587 ms (bit-fields for clvl / clvl_old / isel_old / flags: no gain)
+    __device__ __forceinline__ int inc(int k) const { return (int)(((unsigned)incs >> (2 * k)) & 3u) - 1; }
+    __device__ __forceinline__ void set_inc(int k, int v) { incs = (int)(((unsigned)incs & ~(3u << (2 * k))) | ((unsigned)(v + 1) << (2 * k))); }
     double cpi0, cpi1, cpi2;  // 1/cproj (rt_routines.f90:1671)
     double pa0, pa1, pa2;     // pabs_arr
     double prev;
@@ -181,17 +184,17 @@ __device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S,
     const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
     double c0 = c[0], c1 = c[1], c2 = c[2];
     if (r.clvl == r.clvl_old) {
-        if (r.inc0 != 0) p0 = r.cpi0 * c0 + r.pa0;
-        if (r.inc1 != 0) p1 = r.cpi1 * c1 + r.pa1;
-        if (r.inc2 != 0) p2 = r.cpi2 * c2 + r.pa2;
+        if (r.inc(0) != 0) p0 = r.cpi0 * c0 + r.pa0;
+        if (r.inc(1) != 0) p1 = r.cpi1 * c1 + r.pa1;
+        if (r.inc(2) != 0) p2 = r.cpi2 * c2 + r.pa2;
     } else {
         double cs = P.csize_arr[r.clvl];
-        if (r.inc0 != 0) p0 = r.cpi0 * (c0 - S.sx + 0.5 * (double)r.inc0 * cs);
-        if (r.inc1 != 0) p1 = r.cpi1 * (c1 - S.sy + 0.5 * (double)r.inc1 * cs);
-        if (r.inc2 != 0) p2 = r.cpi2 * (c2 - S.sz + 0.5 * (double)r.inc2 * cs);
-        r.pa0 = r.cpi0 * ((-S.sx) + 0.5 * (double)r.inc0 * cs);
-        r.pa1 = r.cpi1 * ((-S.sy) + 0.5 * (double)r.inc1 * cs);
-        r.pa2 = r.cpi2 * ((-S.sz) + 0.5 * (double)r.inc2 * cs);
+        if (r.inc(0) != 0) p0 = r.cpi0 * (c0 - S.sx + 0.5 * (double)r.inc(0) * cs);
+        if (r.inc(1) != 0) p1 = r.cpi1 * (c1 - S.sy + 0.5 * (double)r.inc(1) * cs);
+        if (r.inc(2) != 0) p2 = r.cpi2 * (c2 - S.sz + 0.5 * (double)r.inc(2) * cs);
+        r.pa0 = r.cpi0 * ((-S.sx) + 0.5 * (double)r.inc(0) * cs);
+        r.pa1 = r.cpi1 * ((-S.sy) + 0.5 * (double)r.inc(1) * cs);
+        r.pa2 = r.cpi2 * ((-S.sz) + 0.5 * (double)r.inc(2) * cs);
     }
     if (p0 < p2) {
         if (p0 < p1) { psel = p0; isel = 1; } else { psel = p1; isel = 2; }
@@ -292,7 +295,7 @@ __device__ __forceinline__ bool step_axis(const DevProblem& P, uint32_t& w, int 
 __device__ __forceinline__ bool next_cell(const DevProblem& P, const SrcInfo& S, Ray& r, int isel, double psel, double c0, double c1, double c2,
                                           bool& inside)
 {
-    const int inc = (isel == 1) ? r.inc0 : (isel == 2) ? r.inc1 : r.inc2;
+    const int inc = (isel == 1) ? r.inc(0) : (isel == 2) ? r.inc(1) : r.inc(2);
     const uint32_t e = P.nbr[6ull * (unsigned long long)r.cc + 2 * (isel - 1) + (inc > 0 ? 1 : 0)];
     inside = (e != DRT_NBR_OUT);
     if (!inside) return true;
@@ -581,7 +584,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
     int my_item = 0;
     Ray r;
     r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
-    r.lam_active = false; r.cx = r.cy = r.cz = 0; r.inc0 = r.inc1 = r.inc2 = 0; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
+    r.lam_active = false; r.cx = r.cy = r.cz = 0; r.incs = 0x15; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
     r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
     long long guard = 0;
 
@@ -656,9 +659,9 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
                             r.ipix_dir = ipix_dir;
                             // incvec (rt_routines.f90:1666-1669)
                             int v;
-                            v = (int)(d0 / P.glepsilon); r.inc0 = max(min(v, 1), -1);
-                            v = (int)(d1 / P.glepsilon); r.inc1 = max(min(v, 1), -1);
-                            v = (int)(d2 / P.glepsilon); r.inc2 = max(min(v, 1), -1);
+                            v = (int)(d0 / P.glepsilon); r.set_inc(0, max(min(v, 1), -1));
+                            v = (int)(d1 / P.glepsilon); r.set_inc(1, max(min(v, 1), -1));
+                            v = (int)(d2 / P.glepsilon); r.set_inc(2, max(min(v, 1), -1));
                             r.cpi0 = 1 / d0; r.cpi1 = 1 / d1; r.cpi2 = 1 / d2;
                             r.I = src_lum / S.norm;
                             r.lam_active = lam_ok && (r.I > 0);
@@ -1269,9 +1272,9 @@ __global__ void __launch_bounds__(256) rt_iobs_kernel(const DevProblem* __restri
         r.cc = nc; r.prev = 0.0; r.isel_old = 0; r.clvl = S.lvl_nc; r.clvl_old = -1; r.cc_new = -1; r.flag_beam = true;
         r.cx = P.cpack[3ull * nc]; r.cy = P.cpack[3ull * nc + 1]; r.cz = P.cpack[3ull * nc + 2];
         int v;
-        v = (int)(d0 / P.glepsilon); r.inc0 = max(min(v, 1), -1);
-        v = (int)(d1 / P.glepsilon); r.inc1 = max(min(v, 1), -1);
-        v = (int)(d2 / P.glepsilon); r.inc2 = max(min(v, 1), -1);
+        v = (int)(d0 / P.glepsilon); r.set_inc(0, max(min(v, 1), -1));
+        v = (int)(d1 / P.glepsilon); r.set_inc(1, max(min(v, 1), -1));
+        v = (int)(d2 / P.glepsilon); r.set_inc(2, max(min(v, 1), -1));
         r.cpi0 = 1 / d0; r.cpi1 = 1 / d1; r.cpi2 = 1 / d2;
         r.pa0 = r.pa1 = r.pa2 = 0;
         double I = src_lum / S.norm;
@@ -1304,9 +1307,9 @@ __global__ void __launch_bounds__(256) rt_iobs_kernel(const DevProblem* __restri
             r.prev = psel; r.isel_old = isel; r.clvl_old = r.clvl;
             const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
             const int clvl = r.clvl;
-            bool inside = step_axis(P, r.cx, r.inc0, isel == 1, clvl, psel, r.cpi0, S.sx, c[0]);
-            inside = inside && step_axis(P, r.cy, r.inc1, isel == 2, clvl, psel, r.cpi1, S.sy, c[1]);
-            inside = inside && step_axis(P, r.cz, r.inc2, isel == 3, clvl, psel, r.cpi2, S.sz, c[2]);
+            bool inside = step_axis(P, r.cx, r.inc(0), isel == 1, clvl, psel, r.cpi0, S.sx, c[0]);
+            inside = inside && step_axis(P, r.cy, r.inc(1), isel == 2, clvl, psel, r.cpi1, S.sy, c[1]);
+            inside = inside && step_axis(P, r.cz, r.inc(2), isel == 3, clvl, psel, r.cpi2, S.sz, c[2]);
             if (!inside) done = true;
             else if (!ccindd_to_cc(P, r.cx, r.cy, r.cz, r.cc, r.clvl)) { err |= ERR_CELL_NOT_FOUND; break; }
         }

@@ -292,7 +292,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
     unsigned long long amask = 0;  // the ray's iq list (sticky, set_iq_list :1860-1893)
     Ray r;
     r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
-    r.lam_active = false; r.cx = r.cy = r.cz = 0; r.inc0 = r.inc1 = r.inc2 = 0; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
+    r.lam_active = false; r.cx = r.cy = r.cz = 0; r.incs = 0x15; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
     r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
     long long guard = 0;
 
@@ -357,9 +357,9 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                             r.clvl_old = -1;
                             r.ipix_dir = ipix_dir;
                             int v;  // incvec (rt_routines.f90:1666-1669)
-                            v = (int)(d0 / P.glepsilon); r.inc0 = max(min(v, 1), -1);
-                            v = (int)(d1 / P.glepsilon); r.inc1 = max(min(v, 1), -1);
-                            v = (int)(d2 / P.glepsilon); r.inc2 = max(min(v, 1), -1);
+                            v = (int)(d0 / P.glepsilon); r.set_inc(0, max(min(v, 1), -1));
+                            v = (int)(d1 / P.glepsilon); r.set_inc(1, max(min(v, 1), -1));
+                            v = (int)(d2 / P.glepsilon); r.set_inc(2, max(min(v, 1), -1));
                             r.cpi0 = 1 / d0; r.cpi1 = 1 / d1; r.cpi2 = 1 / d2;
                             double nx = d0, ny = d1, nz = d2;
                             if (a.scatter && is_reco && level <= 256) {  // "reco" rays read table row 1 (calc_ffn_arr)
