@@ -118,7 +118,6 @@ struct Ray {
     __device__ __forceinline__ int inc(int k) const { return (int)(((unsigned)incs >> (2 * k)) & 3u) - 1; }
     __device__ __forceinline__ void set_inc(int k, int v) { incs = (int)(((unsigned)incs & ~(3u << (2 * k))) | ((unsigned)(v + 1) << (2 * k))); }
     double cpi0, cpi1, cpi2;  // 1/cproj (rt_routines.f90:1671)
-    double pa0, pa1, pa2;     // pabs_arr
     double prev;
     double I;                 // ray_intensity of this lane's wavelength
     double tot_hg;            // HG normalisation: sum over the HEALPix slots of x**-1.5 (calc_ffn_arr, rt_routines.f90:2258)
@@ -183,18 +182,18 @@ __device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S,
     double p0 = pmax, p1 = pmax, p2 = pmax;
     const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
     double c0 = c[0], c1 = c[1], c2 = c[2];
+    // The reference caches pabs_arr = cpi * (-src + 0.5 * inc * csize) while the ray stays at one level and then uses
+    // cpi * c + pabs_arr, which rounds differently from the direct form. The cached value is a function of (cpi, src, inc,
+    // csize(level)) alone, so it is recomputed here bit for bit instead of being kept in six registers per ray.
+    const double cs = P.csize_arr[r.clvl];
     if (r.clvl == r.clvl_old) {
-        if (r.inc(0) != 0) p0 = r.cpi0 * c0 + r.pa0;
-        if (r.inc(1) != 0) p1 = r.cpi1 * c1 + r.pa1;
-        if (r.inc(2) != 0) p2 = r.cpi2 * c2 + r.pa2;
+        if (r.inc(0) != 0) p0 = r.cpi0 * c0 + r.cpi0 * ((-S.sx) + 0.5 * (double)r.inc(0) * cs);
+        if (r.inc(1) != 0) p1 = r.cpi1 * c1 + r.cpi1 * ((-S.sy) + 0.5 * (double)r.inc(1) * cs);
+        if (r.inc(2) != 0) p2 = r.cpi2 * c2 + r.cpi2 * ((-S.sz) + 0.5 * (double)r.inc(2) * cs);
     } else {
-        double cs = P.csize_arr[r.clvl];
         if (r.inc(0) != 0) p0 = r.cpi0 * (c0 - S.sx + 0.5 * (double)r.inc(0) * cs);
         if (r.inc(1) != 0) p1 = r.cpi1 * (c1 - S.sy + 0.5 * (double)r.inc(1) * cs);
         if (r.inc(2) != 0) p2 = r.cpi2 * (c2 - S.sz + 0.5 * (double)r.inc(2) * cs);
-        r.pa0 = r.cpi0 * ((-S.sx) + 0.5 * (double)r.inc(0) * cs);
-        r.pa1 = r.cpi1 * ((-S.sy) + 0.5 * (double)r.inc(1) * cs);
-        r.pa2 = r.cpi2 * ((-S.sz) + 0.5 * (double)r.inc(2) * cs);
     }
     if (p0 < p2) {
         if (p0 < p1) { psel = p0; isel = 1; } else { psel = p1; isel = 2; }
@@ -585,7 +584,7 @@ __device__ void trace_items(const DevProblem& P, const StageArgs& a, const SrcIn
     Ray r;
     r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
     r.lam_active = false; r.cx = r.cy = r.cz = 0; r.incs = 0x15; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
-    r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
+    r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
     long long guard = 0;
 
     for (int chunk_base = 0; chunk_base < n_items; chunk_base += a.cap) {
@@ -1276,7 +1275,7 @@ __global__ void __launch_bounds__(256) rt_iobs_kernel(const DevProblem* __restri
         v = (int)(d1 / P.glepsilon); r.set_inc(1, max(min(v, 1), -1));
         v = (int)(d2 / P.glepsilon); r.set_inc(2, max(min(v, 1), -1));
         r.cpi0 = 1 / d0; r.cpi1 = 1 / d1; r.cpi2 = 1 / d2;
-        r.pa0 = r.pa1 = r.pa2 = 0;
+
         double I = src_lum / S.norm;
         const bool act = lam_ok && I > 0;
         if (il == 0) rays++;

@@ -293,7 +293,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
     Ray r;
     r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
     r.lam_active = false; r.cx = r.cy = r.cz = 0; r.incs = 0x15; r.cpi0 = r.cpi1 = r.cpi2 = 1.0;
-    r.pa0 = r.pa1 = r.pa2 = 0; r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
+    r.prev = 0; r.I = 0; r.tot_hg = 1.0; r.nx = r.ny = r.nz = 0;
     long long guard = 0;
 
     for (int chunk_base = 0; chunk_base < n_items; chunk_base += a.cap) {
