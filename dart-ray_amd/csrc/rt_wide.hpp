@@ -289,6 +289,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
     int my_item = 0;
     int hgpix = 0;                 // row of the HG-normalisation table this ray reads (its pixel; 1 for "reco" rays)
     const double* const hgtab = (nsl <= P.hgnorm_max) ? P.hgnorm[nsl] : nullptr;  // wave-uniform: all rays of this call share nside
+    const double beam_i = 4 * P.pi / (12 * (level * level));  // solid angle of a ray of this level (wave-uniform)
     unsigned long long amask = 0;  // the ray's iq list (sticky, set_iq_list :1860-1893)
     Ray r;
     r.cc = 0; r.clvl = 1; r.clvl_old = -1; r.cc_new = -1; r.isel_old = 0; r.ipix_dir = 0; r.flag_beam = true;
@@ -463,7 +464,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
             double psel = 0.0, length = 0.0;
             int isel = 0;
             int br = 0;
-            double beam_i = 0, beam_f = 0, csize_f = 0, vol_f = 0;
+            double beam_f = 0, csize_f = 0, vol_f = 0;
             // Phase alignment: rays of one source that cross the same cell enter it at nearly the same distance from
             // the source, but after different numbers of steps (different start cells, cell sizes, obliquity). Only
             // the lanes within DRT_PHASE_K cell sizes of the wave's smallest entry distance take this step; the
@@ -488,9 +489,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                     // deposit, the part that does not depend on the wavelength (rt_routines.f90:2362-2557)
                     wc.deps++;
                     wc.lamdep += (DRT_WIDE_CNT_T)__popcll(amask);
-                    const int npix_beam = 12 * (level * level);
-                    beam_i = 4 * P.pi / npix_beam;
-                    const int lv = P.lvl[r.cc];
+                    const int lv = r.clvl;  // = lvl(cc): set with r.cc wherever the ray enters a cell
                     csize_f = P.csize_arr[lv]; vol_f = P.cvol_arr[lv];
                     beam_f = P.carea_arr[lv] / (psel * psel);
                     const bool narrow = (beam_f / P.bm_par <= beam_i) && !r.flag_beam;
