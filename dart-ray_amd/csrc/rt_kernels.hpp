@@ -176,12 +176,12 @@ typedef WaveCountersT<DRT_WIDE_CNT_T> WideCounters;
 #endif
 
 // calc_psel (rt_routines.f90:2307-2351)
-__device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S, Ray& r, double& psel, int& isel)
+__device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S, Ray& r, double& psel, int& isel, double& c0, double& c1, double& c2)
 {
     double pmax = (double)P.pabs_max;
     double p0 = pmax, p1 = pmax, p2 = pmax;
     const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
-    double c0 = c[0], c1 = c[1], c2 = c[2];
+    c0 = c[0]; c1 = c[1]; c2 = c[2];
     // The reference caches pabs_arr = cpi * (-src + 0.5 * inc * csize) while the ray stays at one level and then uses
     // cpi * c + pabs_arr, which rounds differently from the direct form. The cached value is a function of (cpi, src, inc,
     // csize(level)) alone, so it is recomputed here bit for bit instead of being kept in six registers per ray.
@@ -200,6 +200,12 @@ __device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S,
     } else {
         if (p2 < p1) { psel = p2; isel = 3; } else { psel = p1; isel = 2; }
     }
+}
+
+__device__ __forceinline__ void calc_psel(const DevProblem& P, const SrcInfo& S, Ray& r, double& psel, int& isel)
+{
+    double c0, c1, c2;
+    calc_psel(P, S, r, psel, isel, c0, c1, c2);
 }
 
 // find_cc_new2 + calc_outcube (rt_routines.f90:1962-2085). d = ray direction (not inverted).

@@ -478,9 +478,21 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 for (int off = 1; off < 64; off <<= 1) pm = fmin(pm, __shfl_xor(pm, off, 64));
                 go = busy && (r.prev <= pm + a.phase_win * P.csize_arr[r.clvl]);
             }
+            // The next cell of every ray that may go on is looked up HERE, in front of the step's atomics: loads and atomics
+            // share one in-order counter, so a load issued behind them returns only when they have all been performed. The
+            // ray moves there (r.cc, r.clvl) after the deposit, if it goes on at all. (-1 % at one wavelength)
+            int n_cc = 0, n_clvl = 0;
+            bool n_inside = true, n_found = true;
             if (go) {
                 wc.inter++;
-                calc_psel(P, S, r, psel, isel);
+                double cc0, cc1, cc2;
+                calc_psel(P, S, r, psel, isel, cc0, cc1, cc2);
+                {
+                    const int cc_keep = r.cc, clvl_keep = r.clvl;
+                    n_found = next_cell(P, S, r, isel, psel, cc0, cc1, cc2, n_inside);
+                    n_cc = r.cc; n_clvl = r.clvl;
+                    r.cc = cc_keep; r.clvl = clvl_keep;
+                }
                 length = psel - r.prev;
                 if (fabs(length) < P.len_eps * P.csize_arr[r.clvl]) length = 0;
                 if (length < 0) { err |= ERR_NEG_LENGTH; status = ST_GONE; }
@@ -618,10 +630,9 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 r.prev = psel;
                 r.isel_old = isel;
                 r.clvl_old = r.clvl;
-                const double* c = P.ccoord + 3ull * (unsigned long long)r.cc;
-                bool inside = true;
-                if (!next_cell(P, S, r, isel, psel, c[0], c[1], c[2], inside)) { err |= ERR_CELL_NOT_FOUND; busy = false; }
-                if (!inside) busy = false;
+                r.cc = n_cc; r.clvl = n_clvl;
+                if (!n_found) { err |= ERR_CELL_NOT_FOUND; busy = false; }
+                if (!n_inside) busy = false;
             }
             TSTAMP(ts5);
             TACC(t_next, ts4, ts5);
