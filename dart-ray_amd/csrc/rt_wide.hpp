@@ -531,32 +531,37 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                             : (br == 2) ? (hgtab ? hgtab + (unsigned long long)hgpix * L : thg + lane) : p_dens;
                 const int aux_stride = (br == 2 && !hgtab) ? 64 : 1;
                 // the wavelengths some ray of this step still carries (wave-uniform): only those are visited
-                unsigned lo = (br != 0) ? (unsigned)amask : 0u, hi = (br != 0) ? (unsigned)(amask >> 32) : 0u;
-                for (int off = 1; off < 64; off <<= 1) lo |= (unsigned)__shfl_xor((int)lo, off, 64);
-                if (LP > 32) for (int off = 1; off < 64; off <<= 1) hi |= (unsigned)__shfl_xor((int)hi, off, 64);
-                unsigned long long lam_any = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)lo)
-                                             | ((LP > 32) ? ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) : 0ull);
+                unsigned long long lam_any;
+                if constexpr (LP == 1) lam_any = __ballot(br != 0 && (amask & 1ull)) ? 1ull : 0ull;
+                else {
+                    unsigned lo = (br != 0) ? (unsigned)amask : 0u, hi = (br != 0) ? (unsigned)(amask >> 32) : 0u;
+                    for (int off = 1; off < 64; off <<= 1) lo |= (unsigned)__shfl_xor((int)lo, off, 64);
+                    if (LP > 32) for (int off = 1; off < 64; off <<= 1) hi |= (unsigned)__shfl_xor((int)hi, off, 64);
+                    lam_any = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)lo)
+                              | ((LP > 32) ? ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) : 0ull);
+                }
                 // Operands are fetched DRT_OPQ wavelengths at a time into LDS (dens, aux, ray intensity: three loads per
                 // wavelength and lane, issued together and waited for once). gfx950 has ONE in-order counter for loads and
                 // atomics: a load issued after a wavelength's atomics waits for all of them, so fetching per wavelength
                 // drained the atomic queue eleven times per step; per chunk it is two or three.
+                constexpr int OPQ = (LP == 1) ? 1 : DRT_OPQ;  // one wavelength: nothing to chunk
                 while (lam_any) {
-                    int lq[DRT_OPQ];
+                    int lq[OPQ];
                     unsigned long long mq = lam_any;
 #pragma unroll
-                    for (int q = 0; q < DRT_OPQ; q++) { lq[q] = mq ? __ffsll((long long)mq) - 1 : -1; mq &= mq - 1; }
-                    double tdn[DRT_OPQ], tax[DRT_OPQ], tI[DRT_OPQ];
+                    for (int q = 0; q < OPQ; q++) { lq[q] = mq ? __ffsll((long long)mq) - 1 : -1; mq &= mq - 1; }
+                    double tdn[OPQ], tax[OPQ], tI[OPQ];
 #pragma unroll
-                    for (int q = 0; q < DRT_OPQ; q++) {
+                    for (int q = 0; q < OPQ; q++) {
                         tdn[q] = 0.0; tax[q] = 1.0; tI[q] = 0.0;
                         if (lq[q] >= 0 && br != 0 && ((amask >> lq[q]) & 1ull)) {
                             tdn[q] = gload(p_dens + lq[q]); tax[q] = gload(p_aux + lq[q] * aux_stride); tI[q] = IRD(Ilds, lq[q] * 64 + lane);
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < DRT_OPQ; q++) { opq[(3 * q) * 64 + lane] = tdn[q]; opq[(3 * q + 1) * 64 + lane] = tax[q]; opq[(3 * q + 2) * 64 + lane] = tI[q]; }
+                    for (int q = 0; q < OPQ; q++) { opq[(3 * q) * 64 + lane] = tdn[q]; opq[(3 * q + 1) * 64 + lane] = tax[q]; opq[(3 * q + 2) * 64 + lane] = tI[q]; }
 #pragma nounroll
-                    for (int q = 0; q < DRT_OPQ && lam_any; q++) {
+                    for (int q = 0; q < OPQ && lam_any; q++) {
                         const int l = __ffsll((long long)lam_any) - 1;
                         lam_any &= lam_any - 1;
                         const bool act = br != 0 && ((amask >> l) & 1ull);
