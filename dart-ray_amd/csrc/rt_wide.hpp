@@ -60,7 +60,8 @@ typedef ldouble* iptr_t;
 #ifndef DRT_OPQ
 #define DRT_OPQ 4  // wavelengths whose operands (dens, aux, intensity: 3 x 64 doubles each) are staged in LDS at a time
 #endif
-#define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ + 3)
+// + [DRT_OPQ][64] u_final sums of the chunk's wavelengths by leader lane, + 64 ints: the leader lanes in rank order
+#define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ + 3 + 64 * DRT_OPQ + 32 + 1)
 struct HotP {
     int L;
     double tau_thin, cs, en_lim;
@@ -162,8 +163,9 @@ __device__ __forceinline__ double pow_m1p5_f(double x)
 // the loop is VALU-issue-bound and ten of its ~22 vector instructions per ray were readlanes.
 #define DRT_BST 64  // row length of the broadcast staging area
 template <bool BIG>
-__device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long long M, unsigned long long MC, int cc, double U, const ldouble* bst,
-                                             int l, const SlotTabs& T, const HotP& H, const LaneTab& LT, WideCounters& wc)
+__device__ __forceinline__ unsigned long long flush_lambda(const DevProblem& P, unsigned long long M, unsigned long long MC, int cc, double U, const ldouble* bst,
+                                             int l, const SlotTabs& T, const HotP& H, const LaneTab& LT, WideCounters& wc,
+                                             unsigned long long Mbr = 0ull, ldouble* urow = nullptr)
 {
     const int lane = lane_id();
     const unsigned long long Mall = M;
@@ -186,9 +188,13 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
         TSTAMP(tg0);
         const int src = __ffsll((long long)M) - 1;
         const int cc_b = __builtin_amdgcn_readlane(cc, src);
-        const unsigned long long grp = __ballot(cc == cc_b) & Mall;
+        // the group's u_final sum goes to the first lane of the cell among ALL depositing rays of the step (Mbr): the same
+        // lane for every wavelength of the chunk, see the chunk's epilogue in trace_items_w
+        const unsigned long long same = __ballot(cc == cc_b);
+        const unsigned long long grp = same & Mall;
+        const int lead = urow ? __ffsll((long long)(same & Mbr)) - 1 : src;
         M &= ~grp;
-        leaders |= 1ull << src;
+        leaders |= 1ull << lead;
 #ifdef DRT_PROFILE
         wc.n_groups++; wc.n_memb += __popcll(grp);
         if (reg < 0) wc.n_cls2 += __popcll(grp); else if (reg == 0) wc.n_cls0 += __popcll(grp); else wc.n_cls1 += __popcll(grp);
@@ -259,7 +265,12 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
                 if (go) DRT_ATOMIC(H, rowp + p, a2);
             }
         }
-        su_lead = (lane == src) ? su : su_lead;
+        su_lead = (lane == lead) ? su : su_lead;
+    }
+    if (urow) {  // u_final leaves the wave once per chunk of wavelengths, not once per wavelength
+        if ((leaders >> lane) & 1ull) urow[lane] = su_lead;
+        wc.atom += na; wc.atom_lanes += nl;
+        return leaders;
     }
     {
         const bool go = ((leaders >> lane) & 1ull) && su_lead != 0.0;
@@ -268,6 +279,7 @@ __device__ __forceinline__ void flush_lambda(const DevProblem& P, unsigned long 
         if (go) DRT_ATOMIC(H, H.u_final + ((unsigned long long)(unsigned)cc * (unsigned)H.L + (unsigned)l), su_lead);
     }
     wc.atom += na; wc.atom_lanes += nl;
+    return 0ull;
 }
 
 // trace_items of rt_kernels.hpp with lane = ray. Ilds: [L][64] LDS intensities of the wave, thg: [L][64]
@@ -545,7 +557,20 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 // atomics: a load issued after a wavelength's atomics waits for all of them, so fetching per wavelength
                 // drained the atomic queue eleven times per step; per chunk it is two or three.
                 constexpr int OPQ = (LP == 1) ? 1 : DRT_OPQ;  // one wavelength: nothing to chunk
+                // u_final: 256 contiguous bytes per cell at 32 wavelengths. One atomic per wavelength with a lane per cell is
+                // one 64-byte request per (cell, wavelength); the sums of a chunk's wavelengths, gathered in LDS by cell and
+                // sent as ONE instruction with the lanes (cell, wavelength), are one or two requests per cell - the step runs
+                // at the request rate of the memory-side atomic unit.
+                constexpr bool UB = (LP > 1);
+                ldouble* const ubuf = opq + 3 * 64 * DRT_OPQ;                   // [OPQ][64]
+                __attribute__((address_space(3))) int* const lead_lane = (__attribute__((address_space(3))) int*)(ubuf + 64 * DRT_OPQ);
+                const unsigned long long Mbr = __ballot(br != 0);
                 while (lam_any) {
+                    unsigned long long chunk_leaders = 0ull;
+                    if (UB && a.scatter) {
+#pragma unroll
+                        for (int q = 0; q < OPQ; q++) ubuf[q * 64 + lane] = 0.0;
+                    }
                     int lq[OPQ];
                     unsigned long long mq = lam_any;
 #pragma unroll
@@ -597,12 +622,40 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                     __builtin_amdgcn_wave_barrier();
                                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                                    flush_lambda<BIG>(P, M, MC, cc_s, U, bst, l, T, H, LT, wc);
+                                    chunk_leaders |= flush_lambda<BIG>(P, M, MC, cc_s, U, bst, l, T, H, LT, wc, Mbr, UB ? ubuf + q * 64 : nullptr);
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                     __builtin_amdgcn_wave_barrier();
                                 }
                             }
                         }
+                    }
+                    if (UB && chunk_leaders) {
+                        // epilogue of the chunk: lane p = 4 * (rank of a leader) + (slot of the chunk) adds that leader's sum
+                        // of that wavelength to u_final(l, cell of the leader)
+                        if ((chunk_leaders >> lane) & 1ull) lead_lane[__popcll(chunk_leaders & lanemask_lt())] = lane;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const int nlead = __popcll(chunk_leaders);
+                        unsigned na = 0, nl = 0;
+                        for (int p0 = 0; p0 < OPQ * nlead; p0 += 64) {
+                            const int p = p0 + lane, k = p / OPQ, q = p % OPQ;
+                            const bool in = k < nlead;
+                            const int f = in ? lead_lane[k] : 0;
+                            const int c_f = __shfl(cc_s, f, 64);
+                            double v = 0.0;
+                            int l_q = lq[0];
+#pragma unroll
+                            for (int j = 1; j < OPQ; j++) l_q = (q == j) ? lq[j] : l_q;
+                            if (in) v = ubuf[q * 64 + f];
+                            const bool go_u = in && v != 0.0 && l_q >= 0;
+                            const unsigned long long gb_ = __ballot(go_u);
+                            na += (gb_ != 0ull); nl += (unsigned)__popcll(gb_);
+                            if (go_u) DRT_ATOMIC(H, H.u_final + ((unsigned long long)(unsigned)c_f * (unsigned)H.L + (unsigned)l_q), v);
+                        }
+                        wc.atom += na; wc.atom_lanes += nl;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             }
