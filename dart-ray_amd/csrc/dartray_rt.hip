@@ -1032,7 +1032,8 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     // work per source of the previous call of this stage, like the sectors per task) and the emptier steps cost more
     // than the merged atomics save. DRT_PHASE_WINDOW overrides.
     // (one wavelength, bench-sized grid: 0 -> 713 ms, 1 -> 848, 2 -> 753: not bound by the atomic unit; 32 wavelengths: 6.62 -> 5.99 s)
-    a.phase_win = (c->L >= 8 && c->G_want[rt_type & 15] != 4) ? 2.0 : 0.0;
+    // (with u_final batched per chunk, bench step: 0.5 -> 5.18 s, 0.75 -> 4.68, 1 -> 4.43, 1.25 -> 4.35, 1.5 -> 4.35, 2 -> 4.56, 2.5 -> 4.80, 3 -> 4.90)
+    a.phase_win = (c->L >= 8 && c->G_want[rt_type & 15] != 4) ? 1.25 : 0.0;
     if (const char* e = getenv("DRT_PHASE_WINDOW")) a.phase_win = atof(e);
     auto launch = [&](int nblocks) {
         if (c->ray_major) {
