@@ -16,6 +16,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -463,12 +465,29 @@ static int build_dir_tables(drt_ctx* c)
             ring[3 * jr] = th; ring[3 * jr + 1] = sin(th); ring[3 * jr + 2] = cos(th);
         }
         std::vector<double> p0(3ull * 2 * nside * (nside + 1)), p1(3ull * nl4);
-        for (long nr = 1; nr <= nside; nr++)
-            for (long jp = 1; jp <= 4 * nr; jp++) {
-                double ph = (jp - (0 + 1) * 0.5) * (halfpi / nr);
-                size_t o = 3ull * (2ull * nr * (nr - 1) + (jp - 1));
-                p0[o] = ph; p0[o + 1] = sin(ph); p0[o + 2] = cos(ph);
+        // 3.4e7 sines and cosines for the levels up to nside 2048: a few seconds on one host core, so the rings are shared
+        // among threads (every entry is its own libm call: the table does not depend on who computes it)
+        auto fill_p0 = [&](long nr_lo, long nr_hi) {
+            for (long nr = nr_lo; nr <= nr_hi; nr++)
+                for (long jp = 1; jp <= 4 * nr; jp++) {
+                    double ph = (jp - (0 + 1) * 0.5) * (halfpi / nr);
+                    size_t o = 3ull * (2ull * nr * (nr - 1) + (jp - 1));
+                    p0[o] = ph; p0[o + 1] = sin(ph); p0[o + 2] = cos(ph);
+                }
+        };
+        const long nthr = (nside >= 256) ? std::max(1l, std::min(16l, (long)std::thread::hardware_concurrency())) : 1l;
+        if (nthr <= 1) fill_p0(1, nside);
+        else {
+            // ring nr has 4 nr entries: equal shares of the entries = equal shares of nr^2
+            std::vector<std::thread> th;
+            long lo = 1;
+            for (long t = 1; t <= nthr; t++) {
+                const long hi = (t == nthr) ? nside : (long)(nside * sqrt((double)t / (double)nthr));
+                if (hi >= lo) th.emplace_back(fill_p0, lo, hi);
+                lo = std::max(lo, hi + 1);
             }
+            for (auto& x : th) x.join();
+        }
         for (long jp = 1; jp <= nl4; jp++) {
             double ph = (jp - (1 + 1) * 0.5) * (halfpi / nside);
             size_t o = 3ull * (jp - 1);
@@ -653,6 +672,10 @@ static int prepare_start(drt_ctx* c)
     if (!c->have_grid || !c->have_par || c->L < 1) return fail(c, DRT_E_ARG, "rt_prepare(start): grid, params and wavelengths must be set first");
     if (!c->d_dens || c->dens_stars_h.size() != (size_t)c->N * c->L) return fail(c, DRT_E_ARG, "rt_prepare(start): dens_arr and dens_stars_arr must be set first (drt_set_array)");
     const int N = c->N, L = c->L;
+    const bool timing = getenv("DRT_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_0 = tnow();
     set_npix_arr(c);
     // set_en_lim (rt_routines.f90:3137-3158)
     int leaves = 0;
@@ -701,7 +724,9 @@ static int prepare_start(drt_ctx* c)
         }
         if ((rc = dev_upload(c, &c->d_dir_out_sc, sc.data(), sc.size()))) return rc;
     }
+    const auto t_1 = tnow();
     if ((rc = build_dir_tables(c))) return rc;
+    const auto t_2 = tnow();
     if ((rc = dev_zero(c, &c->d_u_fest, (size_t)N * L))) return rc;
     if ((rc = dev_zero(c, &c->d_u_final, (size_t)N * L))) return rc;
     if ((rc = dev_zero(c, &c->d_lum_lost, (size_t)L))) return rc;
@@ -711,7 +736,9 @@ static int prepare_start(drt_ctx* c)
     c->iterations = 0; c->cnflag = 0; c->bm_par_cur = c->par.bm_par; c->part2 = false;
     c->prepared = true;
     if ((rc = ensure_arena(c))) return rc;
-    return upload_problem(c);
+    rc = upload_problem(c);
+    if (timing) fprintf(stderr, "[dartray_rt] rt_prepare(start): sources and uploads %.1f ms, direction tables %.1f ms, fields and arena %.1f ms\n", tms(t_0, t_1), tms(t_1, t_2), tms(t_2, tnow()));
+    return rc;
 }
 
 // create_scaspe + create_i_obs (rt_routines.f90:2784-2852, 2970-3009)
