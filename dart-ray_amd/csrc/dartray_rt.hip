@@ -1060,7 +1060,9 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     // than the merged atomics save. DRT_PHASE_WINDOW overrides.
     // (one wavelength, bench-sized grid: 0 -> 713 ms, 1 -> 848, 2 -> 753: not bound by the atomic unit; 32 wavelengths: 6.62 -> 5.99 s)
     // (with u_final batched per chunk, bench step: 0.5 -> 5.18 s, 0.75 -> 4.68, 1 -> 4.43, 1.25 -> 4.35, 1.5 -> 4.35, 2 -> 4.56, 2.5 -> 4.80, 3 -> 4.90)
-    a.phase_win = (c->L >= 8 && c->G_want[rt_type & 15] != 4) ? 1.25 : 0.0;
+    // (one wavelength, bench-sized grid, after this round's register diet: 0 -> 534 ms, 0.75 -> 585, 1 -> 536, 1.25 -> 511, 1.5 -> 503, 2 -> 513, 3 -> 535;
+    //  config 1, cheap sources: 0 -> 4.9 ms, 1.5 -> 5.2)
+    a.phase_win = (c->G_want[rt_type & 15] != 4) ? 1.5 : 0.0;
     if (const char* e = getenv("DRT_PHASE_WINDOW")) a.phase_win = atof(e);
     auto launch = [&](int nblocks) {
         if (c->ray_major) {
