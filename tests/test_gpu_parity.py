@@ -429,6 +429,55 @@ def test_gpu_matches_oracle_on_baseline_configs(name, pkg, tmp_path):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("mapping", ["ray_major", "lane_per_wavelength"])
+def test_more_than_32_wavelengths_match_the_oracle(mapping, pkg, tmp_path, monkeypatch):
+    """40 wavelengths per ray (the 32 of the TRUST-I list and eight of them again): the <64> instantiations of both
+    kernels - 64-bit wavelength masks, two 32-bit halves in the wave-OR of the live wavelengths, ten operand chunks, rows
+    of 64 doubles in the ray queues - which no BASELINE config reaches (they carry at most 32). Whole run against the C
+    oracle on the 1 801-cell slab: same counts, same number of scattering iterations, fields to 1e-9."""
+    import os
+    monkeypatch.setenv("DRT_RAY_MAJOR", "1" if mapping == "ray_major" else "0")
+    wl = list(range(32)) + [0, 5, 9, 13, 17, 21, 25, 29]
+    case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=2, wavelengths=wl, max_sca_iterations=2)
+    assert case.lnum == 40
+    path = str(tmp_path / "case.bin")
+    case.write(path)
+    nsrc, ndir = case.p_src_pos.shape[0], case.dir_out.shape[0]
+    o = op.Oracle(path, nsrc=nsrc, ndir=ndir)
+    o.set_parallel(1, 0, min(8, os.cpu_count() or 1))
+    g = pkg.DartRayGPU(case)
+    g.rt_prepare("start")
+    for rt in ("precalc_cell", "precalc_src"):
+        o.rt_loop(rt); g.rt_loop(rt)
+    o.rt_mpi("precalc_src"); g.rt_mpi("precalc_src")
+    g.rt_prepare("prep_part2")
+    for rt in ("dir_cell", "dir_src"):
+        o.reset_counters(); o.rt_loop(rt)
+        g.reset_counters(); g.rt_loop(rt)
+        co, cg = o.counters(), g.counters()
+        assert (cg["intersections"], cg["rays"], cg["deposits"]) == (co["intersections"], co["rays"], co["deposits"]), rt
+    o.rt_mpi("dir_src"); g.rt_mpi("dir_src")
+    while True:
+        co_, cg_ = o.scatt_prepare(), g.scatt_prepare()
+        assert co_ == cg_
+        if cg_:
+            break
+        o.reset_counters(); o.rt_loop("scatt")
+        g.reset_counters(); g.rt_loop("scatt")
+        co, cg = o.counters(), g.counters()
+        assert (cg["intersections"], cg["rays"], cg["deposits"]) == (co["intersections"], co["rays"], co["deposits"]), "scatt"
+        o.rt_mpi("scatt"); g.rt_mpi("scatt")
+    assert g.iterations == o.iterations
+    assert relmax(g.u_final, o.u_final) <= RTOL and relelem(g.u_final, o.u_final) <= RTOL_ELEM
+    assert relmax(g.lum_lost, o.lum_lost) <= 1e-7
+    for il in range(g.L):
+        assert relmax(g.scaspe_tot(il), o.scaspe_tot(il)) <= RTOL, il
+    # the repeated wavelengths are copies of their originals
+    for k, il in enumerate([0, 5, 9, 13, 17, 21, 25, 29]):
+        assert relmax(g.u_final[:, 32 + k], g.u_final[:, il]) <= 1e-12
+    g.close(); o.close()
+
+
 def test_fortran_main_on_reference_style_inputs(pkg, tmp_path):
     """dartray_gpu_main reads what the reference's programs read (input namelists, wavelength list, HDF5 main
     and lambda grids, dir_out / point-source files, effective-opacity table) and writes make_output's HDF5 files
