@@ -862,6 +862,51 @@ extern "C" int drt_rt_prepare(drt_ctx* c, int32_t rt_type)
     }
 }
 
+// Longest-processing-time deal of chunks of consecutive sources among np ranks, by expected cost: the chunks (at most `chunk`
+// sources) keep neighbours together, a source that costs more than 1/64 of a rank's share is a chunk of its own; heaviest chunk
+// first to the least loaded rank (ties: the earlier chunk, the lower rank). A pure function of its arguments: every rank computes
+// the same deal from the same costs. owner[k] = rank of source k. (drt_deal_by_cost exposes it for the CPU tests.)
+static void deal_by_cost(const double* cost, size_t n, int np, size_t chunk, std::vector<int>& owner)
+{
+    owner.assign(n, 0);
+    if (np <= 1 || n == 0) return;
+    if (chunk < 1) chunk = 1;
+    double csum = 0;
+    for (size_t k = 0; k < n; k++) csum += cost[k];
+    const double big = csum / np / 64.0;
+    struct Chunk { size_t lo, hi; double cost; };
+    std::vector<Chunk> ch;
+    for (size_t k = 0; k < n;) {
+        Chunk q{k, k, 0.0};
+        while (q.hi < n && q.hi - q.lo < chunk) {
+            const double v = cost[q.hi];
+            if (v > big) { if (q.hi == q.lo) { q.cost = v; q.hi++; } break; }
+            q.cost += v; q.hi++;
+        }
+        ch.push_back(q);
+        k = q.hi;
+    }
+    std::vector<size_t> order(ch.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return ch[x].cost > ch[y].cost; });
+    std::vector<double> load((size_t)np, 0.0);
+    for (size_t k : order) {
+        int r = 0;
+        for (int q = 1; q < np; q++) if (load[(size_t)q] < load[(size_t)r]) r = q;
+        load[(size_t)r] += ch[k].cost;
+        for (size_t m = ch[k].lo; m < ch[k].hi; m++) owner[m] = r;
+    }
+}
+
+extern "C" int drt_deal_by_cost(const double* cost, int64_t n, int32_t np, int32_t chunk, int32_t* owner)
+{
+    if (!cost || !owner || n < 0 || np < 1) return DRT_E_ARG;
+    std::vector<int> o;
+    deal_by_cost(cost, (size_t)n, np, (size_t)std::max(1, (int)chunk), o);
+    for (int64_t k = 0; k < n; k++) owner[k] = o[(size_t)k];
+    return DRT_OK;
+}
+
 // ---- rt_loop ---------------------------------------------------------------------------------------------
 // The sources of one rt_loop call on this rank. Cell sources are shared among the ranks in CHUNKS of consecutive
 // emitting cells dealt round the ranks (block-cyclic; DRT_PARTITION_CHUNK cells per chunk, default 64).
@@ -936,34 +981,11 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool 
         for (int i : list) csum += c->src_pred_h[(size_t)i];
         const bool by_cost = !by_block && !(pe && !strcmp(pe, "cyclic")) && csum > 0;
         if (by_cost) {
-            // Longest-processing-time deal of chunks of consecutive sources, by expected cost: the chunks keep neighbours
-            // together, a source that costs more than 1/64 of a rank's share is a chunk of its own; heaviest chunk first to
-            // the least loaded rank (ties: lower rank). Every rank computes the same deal from the same (all-reduced) costs.
-            const double big = csum / np / 64.0;
-            struct Chunk { size_t lo, hi; double cost; };
-            std::vector<Chunk> ch;
-            for (size_t k = 0; k < n;) {
-                Chunk q{k, k, 0.0};
-                while (q.hi < n && q.hi - q.lo < chunk) {
-                    const double v = c->src_pred_h[(size_t)list[q.hi]];
-                    if (v > big) { if (q.hi == q.lo) { q.cost = v; q.hi++; } break; }
-                    q.cost += v; q.hi++;
-                }
-                ch.push_back(q);
-                k = q.hi;
-            }
-            std::vector<size_t> order(ch.size());
-            for (size_t k = 0; k < order.size(); k++) order[k] = k;
-            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return ch[x].cost > ch[y].cost; });
-            std::vector<double> load((size_t)np, 0.0);
-            std::vector<char> take(ch.size(), 0);
-            for (size_t k : order) {
-                int r = 0;
-                for (int q = 1; q < np; q++) if (load[(size_t)q] < load[(size_t)r]) r = q;
-                load[(size_t)r] += ch[k].cost;
-                if (r == id) take[k] = 1;
-            }
-            for (size_t k = 0; k < ch.size(); k++) if (take[k]) mine.insert(mine.end(), list.begin() + ch[k].lo, list.begin() + ch[k].hi);
+            std::vector<double> cost(n);
+            for (size_t k = 0; k < n; k++) cost[k] = c->src_pred_h[(size_t)list[k]];
+            std::vector<int> owner;
+            deal_by_cost(cost.data(), n, np, chunk, owner);
+            for (size_t k = 0; k < n; k++) if (owner[k] == id) mine.push_back(list[k]);
         } else if (by_block) {
             const size_t lo = n * (size_t)id / np, hi = n * (size_t)(id + 1) / np;
             mine.assign(list.begin() + lo, list.begin() + hi);

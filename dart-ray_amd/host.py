@@ -47,7 +47,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost"]
 
 
 def build(force: bool = False) -> str:
@@ -102,6 +102,8 @@ def lib():
             L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         if hasattr(L, "drt_mark_cost_reduced"):
             L.drt_mark_cost_reduced.argtypes = [vp]
+        if hasattr(L, "drt_deal_by_cost"):
+            L.drt_deal_by_cost.argtypes = [dp, C.c_int64, i32, i32, ip]
         _lib = L
     return _lib
 
@@ -116,6 +118,16 @@ def arena_carve(arena_bytes: int, waves: int, lp: int):
     off = (C.c_uint64 * 10)()
     rc = lib().drt_arena_carve(arena_bytes, waves, lp, C.byref(cap), C.byref(hcap), C.byref(stride), off)
     return None if rc != 0 else (cap.value, hcap.value, stride.value, list(off))
+
+
+def deal_by_cost(cost, np_mpi: int, chunk: int = 64) -> np.ndarray:
+    """drt_deal_by_cost: owner rank of each of len(cost) consecutive emitting cells. Needs no GPU."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    owner = np.empty(cost.size, dtype=np.int32)
+    rc = lib().drt_deal_by_cost(_dp(cost), cost.size, np_mpi, chunk, owner.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise ValueError(f"drt_deal_by_cost: {rc}")
+    return owner
 
 
 class DartRayGPU:

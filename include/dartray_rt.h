@@ -138,6 +138,9 @@ int drt_rt_mpi(drt_ctx *ctx, int32_t rt_type);
  * DRT_A_SRC_COST over the ranks it says so here, and the next cell-source stage deals its sources among the ranks by
  * those costs. Without the call the deal uses a function of lumcell alone (identical on all ranks by construction). */
 int drt_mark_cost_reduced(drt_ctx *ctx);
+/* The deal itself, a pure host function (no context, no GPU): owner[k] = rank of source k of n consecutive emitting cells with
+ * expected costs cost[k], np ranks, chunks of at most `chunk` sources. Exported for tests of the multi-rank logic. */
+int drt_deal_by_cost(const double *cost, int64_t n, int32_t np, int32_t chunk, int32_t *owner);
 
 /* ---- module state out -------------------------------------------------------------------------------- */
 /* Copy a field to/from the host. il selects the wavelength for the scaspe arrays (ignored

@@ -120,3 +120,41 @@ def test_arena_layout_regions_do_not_overlap(pkg):
         assert off[7] % 16 == 0 and off[9] <= stride
     assert seen_ok > 50
     assert pkg.host.arena_carve(1 << 20, 4096, 32) is None  # too small: an error, not a layout
+
+
+def test_deal_by_cost_is_a_balanced_partition_in_chunks(pkg):
+    """The deal of cell sources among ranks (build_src_list, drt_deal_by_cost; the C library's host code, no GPU): every
+    source has exactly one owner, runs of ordinary sources stay together in chunks of at most `chunk`, a source above
+    1/64 of a rank's share is dealt alone, the heaviest rank carries at most the mean plus one chunk, the result is a pure
+    function of the costs (two calls agree), and equal costs give every rank the same number of chunks to within one."""
+    host = pkg.host
+    rng = np.random.default_rng(5)
+    n, npr, chunk = 20000, 8, 64
+    cost = rng.lognormal(0.0, 1.0, n)
+    cost[:200] *= 300.0            # first-level cells: a few sources carry a large part of the work
+    own = host.deal_by_cost(cost, npr, chunk)
+    assert own.shape == (n,) and own.min() >= 0 and own.max() == npr - 1
+    assert np.array_equal(own, host.deal_by_cost(cost, npr, chunk))
+    load = np.array([cost[own == r].sum() for r in range(npr)])
+    big = cost.sum() / npr / 64.0
+    # chunks: maximal runs of one owner never exceed... (two neighbouring chunks may go to the same rank, so look at the
+    # boundaries instead) every change of owner happens at a chunk boundary of the construction
+    k, bounds = 0, {0}
+    while k < n:
+        hi = k
+        while hi < n and hi - k < chunk:
+            if cost[hi] > big:
+                if hi == k:
+                    hi += 1
+                break
+            hi += 1
+        bounds.add(hi); k = hi
+    changes = set(np.flatnonzero(np.diff(own) != 0) + 1)
+    assert changes <= bounds
+    largest_chunk = max(cost[a:b].sum() for a, b in zip(sorted(bounds)[:-1], sorted(bounds)[1:]))
+    assert load.max() <= load.mean() + largest_chunk
+    assert load.max() / load.mean() < 1.02
+    eq = host.deal_by_cost(np.ones(64 * 33), npr, 64)
+    counts = np.bincount(eq, minlength=npr) // 64
+    assert counts.max() - counts.min() <= 1 and counts.sum() == 33
+    assert np.array_equal(host.deal_by_cost(cost, 1, chunk), np.zeros(n, dtype=np.int32))
