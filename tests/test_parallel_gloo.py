@@ -27,12 +27,19 @@ rank, world = dist.get_rank(), dist.get_world_size()
 hdr = np.fromfile(case_path, dtype=np.int32, count=16)
 o = op.Oracle(case_path, nsrc=int(hdr[6]), ndir=int(hdr[7]))
 o.set_parallel(world, rank, 1)
+# the per-source cost vector the GPU library keeps (DRT_A_SRC_COST): this rank knows the costs of its own sources only; rt_mpi
+# sums it and then tells the library (src_cost_done). Here: cost = 1 + cell index for the cells i = rank (mod world).
+marks = []
 def fields():
+    cost = np.zeros(o.N); cost[rank::world] = 1.0 + np.arange(o.N)[rank::world]
     f = {"u_fest": torch.from_numpy(o.u_fest), "u_final": torch.from_numpy(o.u_final),
          "lum_lost": torch.from_numpy(o.lum_lost), "lum_lost_prev": torch.from_numpy(o.lum_lost_prev),
-         "scaspe": [torch.from_numpy(o.scaspe(il)) for il in range(o.L)]}
+         "scaspe": [torch.from_numpy(o.scaspe(il)) for il in range(o.L)],
+         "src_cost": torch.from_numpy(cost), "src_cost_done": lambda: marks.append(1)}
+    fields.cost = cost
     return f
 o.rt_loop("precalc_cell"); o.rt_loop("precalc_src"); parallel.rt_mpi(op.RTT["precalc_src"], fields())
+assert len(marks) == 1 and np.array_equal(fields.cost, 1.0 + np.arange(o.N)), "src_cost was not summed over the ranks"
 o.rt_loop("dir_cell"); o.rt_loop("dir_src"); parallel.rt_mpi(op.RTT["dir_src"], fields())
 while not o.scatt_prepare():
     o.rt_loop("scatt"); parallel.rt_mpi(op.RTT["scatt"], fields())
