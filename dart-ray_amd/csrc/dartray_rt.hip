@@ -1077,7 +1077,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
     a.task_first = 0; a.task_stride = 1;
     a.heavy = nullptr; a.n_heavy = 0; a.record_cost = cell_stage ? 1 : 0;
-    // Phase window (trace_items_w): two cell sizes where deposits dominate; off where a source launches few rays (the
+    // Phase window (trace_items_w): 1.5 cell sizes where deposits dominate; off where a source launches few rays (the
     // work per source of the previous call of this stage, like the sectors per task) and the emptier steps cost more
     // than the merged atomics save. DRT_PHASE_WINDOW overrides.
     // (one wavelength, bench-sized grid: 0 -> 713 ms, 1 -> 848, 2 -> 753: not bound by the atomic unit; 32 wavelengths: 6.62 -> 5.99 s)
