@@ -24,6 +24,13 @@ tot = {"inter": 0, "ms": 0.0}
 def on_stage(name):
     pass
 t0 = time.time()
+# a stage of the large configurations runs for minutes: a sign of life once a minute (a silent GPU job is taken to be hung)
+import threading
+def _heartbeat():
+    while True:
+        time.sleep(60)
+        print(f"    ... {time.time() - t0:.0f} s", flush=True)
+threading.Thread(target=_heartbeat, daemon=True).start()
 def stage(name, fn):
     gpu.reset_counters(); ts = time.time(); fn(); c = gpu.counters()
     tot["inter"] += c["intersections"]; tot["ms"] += c["kernel_ms"]
