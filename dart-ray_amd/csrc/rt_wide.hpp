@@ -118,14 +118,10 @@ __device__ __forceinline__ void deposit_lambda(const HotP& P, double ksca_l, int
     }
     const double v = i_av * length / P.cs / vol_f * S.area_i * beam_i;
     if (br == 3) {
-#ifdef DRT_PRECALC_BATCH
         // precalculation: u_fest takes the road of u_final - summed per cell over the rays of the step and per chunk of
         // wavelengths (flush_lambda with no scattered energy; HotP::u_final points at u_fest in these stages)
         u_add = v;
         if (v != 0.0) wc.uadd++;
-#else
-        if (v != 0.0) { gatomic_add(P.u_fest + ((unsigned long long)cc * P.L + l), v); wc.uadd++; }
-#endif
     } else {
         u_add = v;
         if (v != 0.0) wc.uadd++;
@@ -574,11 +570,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 const unsigned long long Mbr = __ballot(br != 0);
                 while (lam_any) {
                     unsigned long long chunk_leaders = 0ull;
-#ifdef DRT_PRECALC_BATCH
                     if (UB && (a.scatter || precalc)) {
-#else
-                    if (UB && a.scatter) {
-#endif
 #pragma unroll
                         for (int q = 0; q < OPQ; q++) ubuf[q * 64 + lane] = 0.0;
                     }
@@ -622,11 +614,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                             }
                             TSTAMP(td1);
                             TACC(t_dep, td0, td1);
-#ifdef DRT_PRECALC_BATCH
                             if (a.scatter || precalc) {
-#else
-                            if (a.scatter) {
-#endif
                                 const unsigned long long MC = __ballot(C != 0.0);
                                 const unsigned long long M = MC | __ballot(U != 0.0);
                                 if (M) {
@@ -782,9 +770,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
     HotP H;
     H.L = L; H.tau_thin = P.tau_thin; H.cs = P.cs; H.en_lim = P.en_lim;
     H.dens = P.dens; H.u_fest_r = P.u_fest; H.u_fest = P.u_fest; H.u_final = P.u_final;
-#ifdef DRT_PRECALC_BATCH
     if (rt == RTT_PRECALC_SRC || rt == RTT_PRECALC_CELL) H.u_final = P.u_fest;  // the accumulator of these stages
-#endif
 #ifdef DRT_DEBUG_FLAGS
     H.skip_atomics = P.dbg_flags & 1;
 #endif
