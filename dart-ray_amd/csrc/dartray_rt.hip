@@ -107,6 +107,7 @@ struct drt_ctx {
     // cost_kind = that launch's rt_type (-1: nothing measured yet)
     std::vector<double> src_pred_h, cost_lum_h;
     int cost_kind = -1;
+    int algorithm = 0;  // DRT_RTA_MAIN / DRT_RTA_I_OBS (drt_set_algorithm)
     bool cost_synced = false;  // np_mpi > 1: d_src_cost has been summed over the ranks since the launch that measured it
     std::vector<double*> d_scaspe, d_scaspe_prev, d_scaspe_tot, d_tab;
     DevProblem* d_prob = nullptr;
@@ -535,7 +536,7 @@ static int upload_problem(drt_ctx* c)
     }
     P.arena = c->d_arena;
     P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task; P.src_cost = c->d_src_cost;
-    P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap; P.dbg_flags = c->dbg_flags;
+    P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap; P.dbg_flags = c->dbg_flags; P.iobs_healpix = (c->algorithm == DRT_RTA_I_OBS) ? 1 : 0;
     for (int k = 0; k < 14; k++) { P.ring_tab[k] = c->d_ring_tab[k]; P.phi0_tab[k] = c->d_phi0_tab[k]; P.phi1_tab[k] = c->d_phi1_tab[k]; }
     P.tab_max_level = c->tab_max_level;
     for (int k = 0; k < 14; k++) P.hgnorm[k] = c->d_hgnorm[k];
@@ -1447,6 +1448,15 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
     return DRT_OK;
 }
 
+extern "C" int drt_set_algorithm(drt_ctx* c, int32_t rta)
+{
+    if (!c) return DRT_E_ARG;
+    if (rta != DRT_RTA_MAIN && rta != DRT_RTA_I_OBS) return fail(c, DRT_E_ARG, "drt_set_algorithm: %d is neither DRT_RTA_MAIN nor DRT_RTA_I_OBS", rta);
+    c->algorithm = rta;
+    if (c->prepared) return upload_problem(c);
+    return DRT_OK;
+}
+
 extern "C" int drt_mark_cost_reduced(drt_ctx* c)
 {
     if (!c) return DRT_E_ARG;
@@ -1525,6 +1535,12 @@ extern "C" int drt_set_array(drt_ctx* c, int32_t which, int32_t il, const double
         return DRT_OK;
     }
     double* d; size_t n, rows, cols, stride; int rc;
+    if (which == DRT_A_SCASPE_TOT && c->part2 && (c->d_scaspe_tot.empty() || !c->d_scaspe_tot[0])) {
+        // create_scaspe_tot (dartray_hub.f90:155, the i_obs algorithm and restarts: scaspe_tot comes from the host)
+        c->d_scaspe_tot.assign(c->L, nullptr);
+        for (int k = 0; k < c->L; k++) if ((rc = dev_zero(c, &c->d_scaspe_tot[k], (size_t)c->N * c->nstride[k]))) return rc;
+        if ((rc = upload_problem(c))) return rc;
+    }
     if ((rc = field_ptr(c, which, il, &d, &n, &rows, &cols, &stride))) return rc;
     if (n != count) return fail(c, DRT_E_ARG, "field %d holds %zu elements, caller passed %zu", which, n, count);
     if (rows) HIPCHK(c, hipMemcpy2D(d, stride * sizeof(double), host, cols * sizeof(double), cols * sizeof(double), rows, hipMemcpyHostToDevice));

@@ -93,6 +93,8 @@ struct DevProblem {
     // optional debug trace of ray launches: dbg[0] = count, then records of 6 ints
     int* dbg;
     int dbg_cap;
+    int iobs_healpix;  // rt_algorithm 'i_obs' (rt_routines.f90:1538-1548): the scattered light towards an observer is read from the HEALPix
+                       // pixel of scaspe_tot that holds the direction (assign_src_lum), not from the run's own observer slot
     int dbg_flags;  // developer builds (-DDRT_DEBUG_FLAGS): bit 0 = skip the scaspe / u_final atomics of the deposit loop (timing only)
 };
 

@@ -1268,10 +1268,16 @@ __global__ void __launch_bounds__(256) rt_iobs_kernel(const DevProblem* __restri
         if (lam_ok) {
             if (rt == RTT_I_OBS_DIR_SRC) src_lum = P.p_src_lum[(unsigned long long)P.src_cell[nc] * P.L + il];
             else if (rt == RTT_I_OBS_DIR_CELL) src_lum = P.lumcell[(unsigned long long)nc * P.L + il];
-            else src_lum = P.scaspe_tot[il][(unsigned long long)nc * P.nstride[il] + P.npix_hp[il] + j] * P.npix_hp[il];
+            else if (!P.iobs_healpix) src_lum = P.scaspe_tot[il][(unsigned long long)nc * P.nstride[il] + P.npix_hp[il] + j] * P.npix_hp[il];
         }
         const double* sc = P.dir_out_sc + 4ull * j;
         const double sin_dl = sc[0], cos_dl = sc[1], sin_al = sc[2], cos_al = sc[3];
+        if (lam_ok && rt == RTT_I_OBS && P.iobs_healpix) {
+            // assign_src_lum (rt_routines.f90:3043-3071): the pixel of the wavelength's own HEALPix resolution that holds the direction
+            const int kp = P.kp[il];
+            const int ip = (kp >= 0) ? ang2pix_nest_z(P, 1 << kp, cos_dl, P.dir_out[P.ndir + j]) : 0;
+            src_lum = P.scaspe_tot[il][(unsigned long long)nc * P.nstride[il] + ip] * P.npix_hp[il];
+        }
         const double d0 = sin_dl * cos_al, d1 = sin_dl * sin_al, d2 = cos_dl;
         Ray r;
         r.cc = nc; r.prev = 0.0; r.isel_old = 0; r.clvl = S.lvl_nc; r.clvl_old = -1; r.cc_new = -1; r.flag_beam = true;

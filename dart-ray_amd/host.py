@@ -47,7 +47,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm"]
 
 
 def build(force: bool = False) -> str:
@@ -102,6 +102,8 @@ def lib():
             L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         if hasattr(L, "drt_mark_cost_reduced"):
             L.drt_mark_cost_reduced.argtypes = [vp]
+        if hasattr(L, "drt_set_algorithm"):
+            L.drt_set_algorithm.argtypes = [vp, i32]
         if hasattr(L, "drt_deal_by_cost"):
             L.drt_deal_by_cost.argtypes = [dp, C.c_int64, i32, i32, ip]
         _lib = L
@@ -231,6 +233,10 @@ class DartRayGPU:
             fields["lum_lost_prev"] = self.device_tensor("lum_lost_prev")
             fields["scaspe"] = [self.device_tensor("scaspe", il) for il in range(self.L)]
         return fields
+
+    def set_algorithm(self, name: str):
+        """'main' or 'i_obs' (drt_set_algorithm)."""
+        self._chk(self.L_.drt_set_algorithm(self.h, {"main": 0, "i_obs": 1}[name]))
 
     def mark_cost_reduced(self):
         """DRT_A_SRC_COST has been summed over the ranks (drt_mark_cost_reduced)."""

@@ -62,6 +62,11 @@ extern "C" {
                             * rt_loop (zero elsewhere). Steers the task order / rank shares of the next one; with np_mpi > 1 it
                             * is summed over the ranks in rt_mpi like the fields (every source is traced by exactly one rank). */
 
+/* rt_algorithm_ID (rt_routines.f90:232-250) as far as it changes the path: the stellar-emission run, and the i_obs algorithm
+ * (dartray_i_obs, dartray_hub.f90:125-168: observer passes for new directions from a stored scaspe_tot) */
+#define DRT_RTA_MAIN 0
+#define DRT_RTA_I_OBS 1
+
 typedef struct drt_ctx drt_ctx;
 
 /* Scalars of rt_routines.f90 / smooth_grid_routines.f90 that steer the path. */
@@ -119,6 +124,10 @@ int drt_set_wavelengths(drt_ctx *ctx, int32_t lnum, const double *ksca_arr_norm,
 /* read_p_src (io_routines.f90:620-666): ccoord_p_src(3,nsrc), lum_p_src_arr(lnum,nsrc) */
 int drt_set_point_sources(drt_ctx *ctx, int32_t tot_p_src, const double *ccoord_p_src, const double *lum_p_src_arr);
 /* read_dir_out (io_routines.f90:520-570): dir_i_out(tot_ndir,2) */
+/* rta_main (default) or rta_i_obs: in the latter rt_loop_iobs(rtt_i_obs) takes the scattered luminosity towards an observer from
+ * the HEALPix pixel of scaspe_tot that holds the direction (assign_src_lum, rt_routines.f90:1538-1548, 3043-3071); scaspe_tot is
+ * handed over with drt_set_array(DRT_A_SCASPE_TOT) after drt_rt_prepare(rtt_prep_part2). */
+int drt_set_algorithm(drt_ctx *ctx, int32_t rta);
 int drt_set_observers(drt_ctx *ctx, int32_t tot_ndir, const double *dir_i_out);
 
 /* ---- the three entry points + rt_prepare ---------------------------------------------------------- */

@@ -193,6 +193,7 @@ struct orc_ctx {
     double *ccoord, *csize, *dens, *dens_stars;
     double *csize_arr, *carea_arr, *cvol_arr;
     double *ksca_norm, *gsca, *p_src_pos, *p_src_lum, *dir_out;
+    int rta_i_obs; /* rt_algorithm_ID == rta_i_obs */
     /* set_npix_arr */
     int *npix_arr, *npix_hp_arr, *kp_sca_arr, *ik_sca_arr;
     int nuniq, *npix_unique, *npix_hp_unique, *kp_unique;
@@ -529,6 +530,26 @@ void orc_destroy(orc_ctx *c)
 }
 
 void orc_set_parallel(orc_ctx *c, int np, int id, int nthreads) { c->np = np; c->id = id; c->nthreads = nthreads < 1 ? 1 : nthreads; }
+/* rt_algorithm_ID (rt_routines.f90:232-250): 0 = rta_main, 1 = rta_i_obs - the only place where the path looks at it is the
+ * source luminosity of rt_loop_iobs(rtt_i_obs), rt_routines.f90:1538-1548 */
+void orc_set_algorithm(orc_ctx *c, int rta) { c->rta_i_obs = (rta == 1); }
+/* new observer directions (dartray_i_obs reads another file_dir_out than the main run): theta[ndir] then phi[ndir]; i_obs is zeroed
+ * like create_i_obs does (rt_routines.f90:2970-2980) */
+void orc_set_dir_out(orc_ctx *c, const double *dir_out)
+{
+    memcpy(c->dir_out, dir_out, (size_t)c->ndir * 16);
+    memset(c->i_obs, 0, (size_t)c->ndir * (c->N + c->nsrc) * c->L * sizeof(double));
+}
+/* calc_total_luminosity, rt_routines.f90:605-660: lumcell back to the stellar emission (dartray_i_obs, dartray_hub.f90:139) */
+void orc_calc_total_luminosity(orc_ctx *c)
+{
+    for (int i = 0; i < c->N; i++) {
+        for (int il = 0; il < c->L; il++) c->lumcell[(size_t)i * c->L + il] = 0.0;
+        if (c->cchild[i] != -1) continue;
+        double v = c->csize[i] * c->csize[i] * c->csize[i];
+        for (int il = 0; il < c->L; il++) c->lumcell[(size_t)i * c->L + il] = c->dens_stars[(size_t)i * c->L + il] * v;
+    }
+}
 
 /* ---- thread state ------------------------------------------------------------------------------- */
 static void ts_init(const orc_ctx *c, tstate *t)
@@ -1195,9 +1216,14 @@ void orc_rt_loop_iobs(orc_ctx *c, int rt_type)
             for (int j = 0; j < c->ndir; j++) {
                 memset(t.i_obs_temp, 0, L * sizeof(double));
                 double theta = c->dir_out[j], phi = c->dir_out[c->ndir + j];
-                if (rt_type == ORC_RTT_I_OBS)
-                    for (int il = 0; il < L; il++)
-                        t.src_lum_ray[il] = t.scaspe_temp[il][c->npix_hp_arr[il] + j] * c->npix_hp_arr[il];
+                if (rt_type == ORC_RTT_I_OBS) {
+                    if (!c->rta_i_obs) {
+                        for (int il = 0; il < L; il++)
+                            t.src_lum_ray[il] = t.scaspe_temp[il][c->npix_hp_arr[il] + j] * c->npix_hp_arr[il];
+                    } else {  /* :1544-1546: the HEALPix pixel that holds the direction */
+                        assign_src_lum(c, &t, theta, phi, t.src_lum_ray);
+                    }
+                }
                 t.nside = NSIDE_MIN; /* `nside` keeps its last value in the reference; unused by the i_obs branch of deposit */
                 ray_tracing(c, &t, i, phi, theta, c->lvl[i], t.src_lum_ray, 0.0, 0, RAY_I_OBS, 0, i);
                 double *dst = c->i_obs + ((size_t)j * (c->N + c->nsrc) + sid) * L;

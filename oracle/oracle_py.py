@@ -67,6 +67,9 @@ def lib():
         L.orc_src_cell.restype = C.POINTER(C.c_int32)
         L.orc_sed.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.orc_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.orc_set_algorithm.argtypes = [C.c_void_p, C.c_int]
+        L.orc_calc_total_luminosity.argtypes = [C.c_void_p]
+        L.orc_set_dir_out.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.orc_reset_counters.argtypes = [C.c_void_p]
         L.orc_pix2ang_nest.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_ang2pix_nest.argtypes = [C.c_int, C.c_double, C.c_double]
@@ -103,6 +106,16 @@ class Oracle:
 
     def set_parallel(self, np_=1, id_=0, nthreads=1):
         self.L_.orc_set_parallel(self.h, np_, id_, nthreads)
+
+    def set_algorithm(self, name: str): self.L_.orc_set_algorithm(self.h, {"main": 0, "i_obs": 1}[name])
+
+    def set_dir_out(self, dir_out: np.ndarray):
+        """dir_out[ndir][2] = (theta, phi); also zeroes i_obs (create_i_obs)."""
+        d = np.ascontiguousarray(np.asarray(dir_out, dtype=np.float64).T)   # theta[ndir] then phi[ndir]
+        assert d.shape == (2, self.ndir)
+        self.L_.orc_set_dir_out(self.h, d.ctypes.data_as(C.POINTER(C.c_double)))
+
+    def calc_total_luminosity(self): self.L_.orc_calc_total_luminosity(self.h)
 
     def rt_loop(self, rt): self.L_.orc_rt_loop(self.h, RTT[rt] if isinstance(rt, str) else rt)
     def rt_loop_iobs(self, rt): self.L_.orc_rt_loop_iobs(self.h, RTT[rt] if isinstance(rt, str) else rt)

@@ -9,7 +9,8 @@
 !> outputs go to "<prefix>.out" and become the golden fixtures under tests/golden/.
 !>
 !> usage: ref_driver <case.bin> <out-prefix> [stages]
-!>   stages: bitmask, 1=precalc 2=direct 4=iobs-direct 8=scattering 16=iobs-scatt (default 31)
+!>   stages: bitmask, 1=precalc 2=direct 4=iobs-direct 8=scattering 16=iobs-scatt (default 31),
+!>           32 = afterwards the i_obs algorithm (dartray_i_obs) for other observer directions, written to "<prefix>.iobs"
 program ref_driver
   use smooth_grid_routines
   use healpix_routines
@@ -230,6 +231,38 @@ program ref_driver
      if (ndir > 0) then
         write(uo) i_obs_arr
         write(uo) sed_tot
+     endif
+
+     ! ------------------------------------------------------------- dartray_i_obs (dartray_hub.f90:125-168)
+     ! The i_obs algorithm for OTHER observer directions, on the scaspe_tot of this run (kept in memory where the reference
+     ! reads it back from its file, :155-157). Its only effect on the path: rt_loop_iobs(rtt_i_obs) takes the scattered
+     ! luminosity from the HEALPix pixel holding the direction (rt_routines.f90:1538-1548).
+     if (iand(stages,32) /= 0 .and. ndir > 0) then
+        rt_algorithm = 'i_obs'; rt_algorithm_ID = rta_i_obs
+        do j = 0, tot_ndir-1
+           dir_i_out(j,1) = 0.5_real64*dir_i_out(j,1) + 0.3_real64
+           dir_i_out(j,2) = 0.5_real64*dir_i_out(j,2) + 0.4_real64
+        enddo
+        open(newunit=un, file=trim(fout)//'.iobs', access='stream', form='unformatted', status='replace')
+        write(un) int(z'44524F32', kind=int32), tot_ncell, lnum, ndir, nsrc
+        write(un) dir_i_out
+        rt_type = rtt_start
+        call calc_total_luminosity                      ! :139: lumcell back to the stellar emission
+        call create_i_obs                               ! :140: zeroes i_obs_arr
+        rt_type = rtt_i_obs_dir_src                     ! :141-144
+        call rt_loop_iobs
+        rt_type = rtt_i_obs_dir_cell
+        call rt_loop_iobs
+        call drv_sed(sed_dir)
+        write(un) i_obs_arr
+        write(un) sed_dir
+        rt_type = rtt_i_obs                             ! :160-163
+        call calc_total_luminosity_sca
+        call rt_loop_iobs
+        call drv_sed(sed_tot)
+        write(un) i_obs_arr
+        write(un) sed_tot
+        close(un)
      endif
   endif
   write(uo) t_pre, t_dir, t_sca, t_iobs

@@ -57,6 +57,34 @@ def test_oracle_matches_reference(name, golden):
     o.close()
 
 
+@pytest.mark.parametrize("name", ["cube65", "blobB"])
+def test_oracle_i_obs_algorithm_matches_reference(name, golden):
+    """dartray_i_obs (dartray_hub.f90:125-168): after a main run the observer passes are repeated for OTHER directions with
+    rt_algorithm_ID = rta_i_obs, the scattered light towards an observer being read from the HEALPix pixel of scaspe_tot
+    that holds the direction (rt_routines.f90:1538-1548, assign_src_lum :3043). Fixture: the unmodified reference modules
+    driven through exactly this sequence (oracle/ref_driver.f90 stage 32, oracle/make_golden_iobs.py)."""
+    import os
+    z, path = golden(name)
+    a = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_iobsalg.npz")))
+    hdr = np.frombuffer(z["case_bin"][:64].tobytes(), dtype=np.int32)
+    nsrc, ndir = int(hdr[6]), int(hdr[7])
+    o = op.Oracle(path, nsrc=nsrc, ndir=ndir)
+    o.run_all(31)
+    assert relmax(o.i_obs[:ndir], z["i_obs"]) <= RTOL_U
+    o.set_algorithm("i_obs")
+    o.set_dir_out(a["dir_alg"])
+    o.calc_total_luminosity()
+    o.rt_loop_iobs("i_obs_dir_src"); o.rt_loop_iobs("i_obs_dir_cell")
+    assert relmax(o.i_obs[:ndir], a["i_obs_alg_dir"]) <= RTOL_U
+    assert relmax(o.sed()[:ndir], a["sed_alg_dir"]) <= RTOL_U
+    o.iobs_prepare(); o.rt_loop_iobs("i_obs")
+    assert relmax(o.i_obs[:ndir], a["i_obs_alg"]) <= RTOL_U
+    assert relmax(o.sed()[:ndir], a["sed_alg"]) <= RTOL_U
+    # the scattered part is there and differs from what the run's own observer slots would give for the old directions
+    assert float((a["i_obs_alg"] - a["i_obs_alg_dir"]).max()) > 0
+    o.close()
+
+
 def test_healpix_roundtrip():
     """ang2pix_nest(pix2ang_nest(p)) == p for every pixel, nside <= 64 (healpix_routines.f90:30,238)."""
     import ctypes as C
