@@ -429,6 +429,42 @@ def test_gpu_matches_oracle_on_baseline_configs(name, pkg, tmp_path):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("name", ["cube65", "blobB"])
+def test_i_obs_algorithm_matches_reference(name, golden, pkg):
+    """dartray_i_obs (dartray_hub.f90:125-168) through the C ABI: a main run leaves scaspe_tot; a second context with
+    OTHER observer directions and drt_set_algorithm(DRT_RTA_I_OBS) takes it over (drt_set_array, the HEALPix part is what
+    counts) and runs the three observer passes. Fixture: the unmodified reference modules driven through this sequence."""
+    import copy
+    import os
+    z, path = golden(name)
+    a = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_iobsalg.npz")))
+    case = pkg.grids.read_case(path, name)
+    main = pkg.DartRayGPU(case)
+    main.run_all(31)
+    assert relmax(main.i_obs, z["i_obs"]) <= RTOL
+    tot = [main.scaspe_tot(il) for il in range(main.L)]
+    main.close()
+    case_b = copy.copy(case)
+    case_b.dir_out = np.ascontiguousarray(a["dir_alg"])
+    g = pkg.DartRayGPU(case_b)
+    g.set_algorithm("i_obs")
+    g.rt_prepare("start")
+    g.rt_prepare("prep_part2")
+    with pytest.raises(pkg.host.DartRayError):
+        g.rt_prepare("i_obs")                      # no scaspe_tot yet
+    for il in range(g.L):
+        t = tot[il].copy()
+        t[:, g.npix_hp[il]:] = 0.0                 # the observer slots of the main run mean nothing here
+        g.set_array("scaspe_tot", t, il)
+    g.rt_loop_iobs("i_obs_dir_src"); g.rt_loop_iobs("i_obs_dir_cell")
+    assert relmax(g.i_obs, a["i_obs_alg_dir"]) <= RTOL
+    assert relmax(g.sed(), a["sed_alg_dir"]) <= 1e-9
+    g.rt_prepare("i_obs"); g.rt_loop_iobs("i_obs")
+    assert relmax(g.i_obs, a["i_obs_alg"]) <= RTOL and relelem(g.i_obs, a["i_obs_alg"]) <= RTOL_ELEM
+    assert relmax(g.sed(), a["sed_alg"]) <= 1e-9
+    g.close()
+
+
 @pytest.mark.parametrize("mapping", ["ray_major", "lane_per_wavelength"])
 def test_more_than_32_wavelengths_match_the_oracle(mapping, pkg, tmp_path, monkeypatch):
     """40 wavelengths per ray (the 32 of the TRUST-I list and eight of them again): the <64> instantiations of both
