@@ -156,6 +156,11 @@ module dartray_c
        integer(c_int32_t), intent(out) :: cells(*), count
      end function drt_get_sources
      ! multi-GPU: one rank per GPU, rt_mpi's MPI_Allreduce becomes ncclAllReduce (RCCL over xGMI) on the device buffers
+     integer(c_int) function drt_set_algorithm(ctx, rta) bind(C, name='drt_set_algorithm')
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: rta
+     end function drt_set_algorithm
      integer(c_int) function drt_mark_cost_reduced(ctx) bind(C, name='drt_mark_cost_reduced')
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx
@@ -206,6 +211,9 @@ module dartray_state
   integer :: rt_type, iterations, max_sca_iterations, np_mpi, id_mpi
   logical :: main_prc
   logical :: file_restore = .FALSE., file_restore_part1 = .FALSE.        ! io_routines.f90:137-140, set by check_files
+  integer :: rt_algorithm_ID = 0                                           ! rt_routines.f90:48
+  integer, parameter :: rta_main = 0, rta_i_obs = 1                        ! rt_routines.f90:236-238
+  logical :: only_direct_rt = .FALSE., print_output_part2 = .FALSE.       ! rt_routines.f90:518, io_routines.f90:128
   ! rt_type ids, rt_routines.f90:195-217
   integer, parameter :: rtt_start = 0, rtt_precalc_cell = 1, rtt_precalc_src = 2, rtt_output_part1 = 3, &
        rtt_prep_part2 = 4, rtt_dir_cell = 5, rtt_i_obs_dir_cell = 6, rtt_dir_src = 7, rtt_i_obs_dir_src = 8, &
@@ -228,7 +236,7 @@ module dartray_hub_gpu
        accuracy, cs, dist_obs, modelsize, x_wall_on, y_wall_on, z_wall_on, cnflag, done, limit_scattering_iterations, &
        x_wall_coord, y_wall_coord, z_wall_coord, rt_type, iterations, max_sca_iterations, np_mpi, id_mpi, main_prc, &
        rtt_start, rtt_precalc_cell, rtt_precalc_src, rtt_output_part1, rtt_prep_part2, rtt_dir_cell, rtt_i_obs_dir_cell, &
-       rtt_dir_src, rtt_i_obs_dir_src, rtt_output_part2, rtt_scatt, rtt_i_obs
+       rtt_dir_src, rtt_i_obs_dir_src, rtt_output_part2, rtt_scatt, rtt_i_obs, rt_algorithm_ID, rta_main, rta_i_obs, only_direct_rt
 #else
   use dartray_state
 #endif
@@ -246,10 +254,14 @@ module dartray_hub_gpu
   !> file_restore / file_restore_part1; read_output (io_routines.f90:1900, case rtt_start) fills u_fest_arr, or u_final_arr,
   !> scaspe_arr, lum_lost and i_obs_arr, from the files of an earlier run. Left null, every run starts from the beginning.
   procedure(output_hook), pointer :: check_files => null(), read_output => null()
+  !> dartray_i_obs: fills scaspe_tot_arr (HEALPix part) from the scaspe_tot files of the main run (read_output, case
+  !> rtt_read_scaspe_tot, io_routines.f90:1988-1995); the arrays are allocated by the caller.
+  procedure(output_hook), pointer :: read_scaspe_tot => null()
 #ifdef DRT_REAL_MODULES
   ! io_routines.f90:137-140; that module needs the HDF5 Fortran modules, which amdflang cannot read in this image, so the
   ! link test keeps the two flags here
   logical :: file_restore = .FALSE., file_restore_part1 = .FALSE.
+  logical :: print_output_part2 = .FALSE.   ! io_routines.f90:128, the same reason
 #endif
 contains
 
@@ -414,6 +426,12 @@ contains
     integer(c_size_t) :: n
     n = int(lnum, c_size_t)*int(tot_ncell, c_size_t)
     select case (stage)
+    case (rtt_i_obs_dir_cell)      ! dartray_i_obs: the observer arrays alone
+       if (tot_ndir > 0) then
+          if (.not. allocated(i_obs_arr)) allocate(i_obs_arr(0:lnum-1, 0:tot_ncell+tot_p_src-1, 0:tot_ndir-1))
+          call gpu_check(drt_get_array(gpu_ctx, DRT_A_I_OBS, 0, i_obs_arr, &
+               int(lnum, c_size_t)*int(tot_ncell+tot_p_src, c_size_t)*int(tot_ndir, c_size_t)), 'i_obs_arr')
+       endif
     case (rtt_output_part1)
        if (.not. allocated(u_fest_arr)) allocate(u_fest_arr(0:lnum-1, 0:tot_ncell-1))
        call gpu_check(drt_get_array(gpu_ctx, DRT_A_U_FEST, 0, u_fest_arr, n), 'u_fest_arr')
@@ -536,6 +554,52 @@ contains
        if (done) exit
     enddo
   end subroutine dartray_main
+
+  !> dartray_i_obs (dartray_hub.f90:125-168), stellar emission: the observer passes for the directions of THIS run's
+  !> file_dir_out on the fields of an earlier main run - direct light from the grid, scattered light from the HEALPix part
+  !> of that run's scaspe_tot files (read_scaspe_tot hook). Output through make_output (reset_filenames' names).
+  subroutine dartray_i_obs()
+    integer :: i
+    call gpu_check(drt_set_algorithm(gpu_ctx, int(rta_i_obs, c_int32_t)), 'drt_set_algorithm')
+    rt_type = rtt_start                 ! prepare_p_src, calc_total_luminosity (:137-139)
+    call rt_prepare
+    rt_type = rtt_prep_part2            ! create_scaspe, create_i_obs (:138, :140)
+    call rt_prepare
+    rt_type = rtt_i_obs_dir_src
+    call rt_loop_iobs
+    rt_type = rtt_i_obs_dir_cell
+    call rt_loop_iobs
+    rt_type = rtt_output_part2
+    if (print_output_part2) then
+       call calc_sed
+       call gpu_sync_to_host(rtt_i_obs_dir_cell)
+       if (associated(make_output)) call make_output()
+    endif
+    if (only_direct_rt) return
+    ! create_scaspe_tot + read_output(rtt_read_scaspe_tot) (:155-157)
+    if (.not. associated(read_scaspe_tot)) then
+       print *, 'STOP(dartray_i_obs): no reader for the scaspe_tot files (read_scaspe_tot)'
+       stop 1
+    endif
+    if (.not. allocated(scaspe_tot_arr)) then
+       allocate(scaspe_tot_arr(0:lnum-1))
+       do i = 0, lnum-1
+          allocate(scaspe_tot_arr(i)%a(0:npix_arr(i)-1, 0:tot_ncell-1))
+          scaspe_tot_arr(i)%a = 0
+       enddo
+    endif
+    call read_scaspe_tot()
+    do i = 0, lnum-1
+       call gpu_check(drt_set_array(gpu_ctx, DRT_A_SCASPE_TOT, int(i, c_int32_t), scaspe_tot_arr(i)%a, &
+            int(npix_arr(i), c_size_t)*int(tot_ncell, c_size_t)), 'scaspe_tot_arr')
+    enddo
+    rt_type = rtt_i_obs
+    call rt_prepare
+    call rt_loop_iobs
+    call calc_sed
+    call gpu_sync_to_host(rtt_i_obs_dir_cell)
+    if (associated(make_output)) call make_output()
+  end subroutine dartray_i_obs
 
   subroutine gpu_finalize()
     integer(c_int) :: rc

@@ -33,6 +33,15 @@ program dartray_gpu_main
      stop
   endif
   call gpu_grid_initialize
+  if (rt_algorithm_ID == rta_i_obs) then
+     ! dartray_i_obs.f90 of the reference: observer passes for this input's directions on the scaspe_tot files of a main run
+     make_output => make_output_i_obs_hdf5
+     read_scaspe_tot => read_scaspe_tot_hdf5
+     call dartray_i_obs
+     call gpu_finalize
+     print '(a)', 'dartray_gpu_main: done (i_obs algorithm)'
+     stop
+  endif
   make_output => make_output_hdf5
   check_files => check_files_hdf5
   read_output => read_output_hdf5

@@ -47,6 +47,17 @@ module dartray_io_c
        integer(c_int64_t), intent(in) :: fdims(*)
        real(c_double), intent(out) :: data(*)
      end function drt_io_read_array
+     integer(c_int) function drt_io_array_dims(path, dsetname, rank, fdims) bind(C, name='drt_io_array_dims')
+       import :: c_int, c_char, c_int64_t
+       character(kind=c_char), intent(in) :: path(*), dsetname(*)
+       integer(c_int), value :: rank
+       integer(c_int64_t), intent(out) :: fdims(*)
+     end function drt_io_array_dims
+     integer(c_int) function drt_io_read_int(path, dsetname, v) bind(C, name='drt_io_read_int')
+       import :: c_int, c_char, c_int32_t
+       character(kind=c_char), intent(in) :: path(*), dsetname(*)
+       integer(c_int32_t), intent(out) :: v
+     end function drt_io_read_int
      integer(c_int) function drt_io_add_int(path, dsetname, v) bind(C, name='drt_io_add_int')
        import :: c_int, c_char, c_int32_t
        character(kind=c_char), intent(in) :: path(*), dsetname(*)
@@ -92,9 +103,9 @@ module dartray_io_gpu
   real(kind=real64) :: lambda_ref, max_lambda_stars, min_lambda_dust, tau_cell_max, npixel_maps, map_size_factor, z_sun
   integer :: ind_i_obs(0:max_n_input-1), ind_out_maps(0:max_n_input-1), n_dust_size_qabs(0:3), n_dust_wave_qabs, &
        n_dust_temp_cal(0:3), kp_maps, n_int_rf_bins
-  logical :: print_scaspe_tot, print_output_part1, print_output_part2, print_scaspe_part2, restore_file_mpi, &
+  logical :: print_scaspe_tot, print_output_part1, print_scaspe_part2, restore_file_mpi, &   ! print_output_part2, only_direct_rt: dartray_state
        use_lambda_grid, use_dir_out, use_pos_obs, use_p_src, print_psel_av, sequential_scattering, print_sed, &
-       input_av_opacities, no_communications, no_dust_rt, only_direct_rt, test_run, print_maps, print_maps_in, &
+       input_av_opacities, no_communications, no_dust_rt, test_run, print_maps, print_maps_in, &
        use_stellar_library
   namelist /dartray_input_strings/ label_model_lambda_grid, label_model_out, label_model_out_i_obs, file_dir_out, &
        file_pos_obs, file_p_src, file_lambda_list, dir_runs, dir_grid, grid_file, rt_algorithm, units_luminosity, &
@@ -423,10 +434,17 @@ contains
     error = .FALSE.
     select case (trim(adjustl(rt_algorithm)))
     case ('main')
+       rt_algorithm_ID = rta_main
+    case ('i_obs')                       ! io_routines.f90:2778-2779
+       rt_algorithm_ID = rta_i_obs
+       if (label_model_out_i_obs == 'not_provided') label_model_out_i_obs = label_model_out   ! :2898-2902
+       if (.not. use_dir_out) then
+          print *, 'ERROR: rt_algorithm = ''i_obs'' needs observer directions (use_dir_out, file_dir_out)'; error = .TRUE.
+       endif
     case ('not_provided')
        print *, 'ERROR: Input rt_algorithm missing'; error = .TRUE.
     case default
-       print *, 'ERROR: rt_algorithm = ', trim(rt_algorithm), ' is outside the GPU path (stellar-emission RT: rt_algorithm = ''main'')'
+       print *, 'ERROR: rt_algorithm = ', trim(rt_algorithm), ' is outside the GPU path (stellar-emission RT: rt_algorithm = ''main'' or ''i_obs'')'
        error = .TRUE.
     end select
     if (dir_runs == 'not_provided') then
@@ -626,13 +644,23 @@ contains
     np_mpi = 1; id_mpi = 0; main_prc = .TRUE.
   end subroutine grid_initialize
 
-  subroutine out_name(lambda, what, path)
+  !> set_filenames (io_routines.f90:720-794); int_names: the names reset_filenames (:797-830) gives the observer arrays and SEDs
+  !> of the i_obs algorithm ('grid_<label_model_out_i_obs>_..._int.h5')
+  subroutine out_name(lambda, what, path, int_names)
     real(kind=real64), intent(in) :: lambda
     character(len=*), intent(in) :: what
     character(len=*), intent(out) :: path
+    logical, intent(in), optional :: int_names
     character(kind=c_char) :: fname(512)
     integer :: i
-    call io_check(drt_io_filename(fname, int(512, c_size_t), cstr(label_model_out), lambda, cstr(what), cstr('')), 'set_filenames')
+    logical :: alt
+    alt = .FALSE.
+    if (present(int_names)) alt = int_names
+    if (alt) then
+       call io_check(drt_io_filename(fname, int(512, c_size_t), cstr(label_model_out_i_obs), lambda, cstr(what), cstr('_int')), 'reset_filenames')
+    else
+       call io_check(drt_io_filename(fname, int(512, c_size_t), cstr(label_model_out), lambda, cstr(what), cstr('')), 'set_filenames')
+    endif
     path = trim(adjustl(dir_runs))//'/'
     do i = 1, 512
        if (fname(i) == c_null_char) exit
@@ -731,6 +759,67 @@ contains
     endif
   end subroutine read_output_hdf5
 
+  !> read_output, case rtt_read_scaspe_tot (io_routines.f90:1988-1995) + find_out_tot_ndir_scaspe (:2566-2651): the scaspe_tot
+  !> files of the main run hold npix_hp + (that run's number of observer directions) rows per cell; the HEALPix rows go to
+  !> scaspe_tot_arr, whose remaining rows (this run's directions) stay zero - the i_obs algorithm never reads them.
+  subroutine read_scaspe_tot_hdf5()
+    character(len=3*lcar) :: path
+    integer :: i, nhp
+    integer(c_int32_t) :: nside_read
+    integer(c_int64_t) :: d2(2)
+    real(kind=real64), allocatable :: tmp2(:,:)
+    do i = 0, lnum-1
+       call out_name(lambda_arr(i), 'scaspe_tot', path)
+       call io_check(drt_io_array_dims(cstr(path), cstr('scaspe_tot'), 2, d2), 'find_out_tot_ndir_scaspe')
+       call io_check(drt_io_read_int(cstr(path), cstr('nside_sca'), nside_read), 'find_out_tot_ndir_scaspe')
+       nhp = 1
+       if (nside_read /= 0) nhp = 12*nside_read**2
+       if (nhp /= npix_hp_arr(i) .or. d2(2) /= tot_ncell .or. d2(1) < nhp) then
+          print *, 'error(read_big_array): the dimensions of the scaspe_tot file do not fit this run. Same kp_sca_max and grid as in the main RT calculation ?'
+          print *, 'file dims =', d2, ' nside_sca =', nside_read, ' expected npix_hp =', npix_hp_arr(i), ' cells =', tot_ncell
+          stop 1
+       endif
+       allocate(tmp2(0:d2(1)-1, 0:tot_ncell-1))
+       call io_check(drt_io_read_array(cstr(path), cstr('scaspe_tot'), 2, d2, tmp2), 'read_scaspe_tot_arr')
+       scaspe_tot_arr(i)%a = 0
+       scaspe_tot_arr(i)%a(0:nhp-1, :) = tmp2(0:nhp-1, :)
+       deallocate(tmp2)
+    enddo
+  end subroutine read_scaspe_tot_hdf5
+
+  !> make_output for the i_obs algorithm (io_routines.f90:1743-1897 with the names of reset_filenames): the observer arrays and
+  !> SEDs of the direct light (rtt_output_part2, when print_output_part2) and of the total light (rtt_i_obs).
+  subroutine make_output_i_obs_hdf5()
+    character(len=3*lcar) :: path
+    integer :: i
+    integer(c_int64_t) :: d2(2)
+    real(kind=real64), allocatable :: tmp2(:,:)
+    logical :: part2
+    if (tot_ndir == 0) return
+    part2 = (rt_type == rtt_output_part2)
+    allocate(tmp2(0:tot_ncell+tot_p_src-1, 0:tot_ndir-1))
+    d2 = [int(tot_ncell+tot_p_src, c_int64_t), int(tot_ndir, c_int64_t)]
+    do i = 0, lnum-1
+       tmp2 = i_obs_arr(i,:,:)
+       if (part2) then
+          call out_name(lambda_arr(i), 'i_obs_part2', path, .TRUE.)
+       else
+          call out_name(lambda_arr(i), 'i_obs', path, .TRUE.)
+       endif
+       call io_check(drt_io_write_array(cstr(path), cstr('i_obs'), 2, d2, tmp2), 'print_i_obs_arr')
+    enddo
+    if (print_sed) then
+       d2 = [int(lnum, c_int64_t), int(tot_ndir, c_int64_t)]
+       if (part2) then
+          call out_name(-1.0_real64, 'sed_dir', path, .TRUE.)
+          call io_check(drt_io_write_array(cstr(path), cstr('sed_arr_dir'), 2, d2, sed_arr_dir), 'print_sed_arr_dir')
+       else
+          call out_name(-1.0_real64, 'sed', path, .TRUE.)
+          call io_check(drt_io_write_array(cstr(path), cstr('sed_arr'), 2, d2, sed_arr), 'print_sed_arr')
+       endif
+    endif
+  end subroutine make_output_i_obs_hdf5
+
   !> make_output (io_routines.f90:1743-1897) through print_big_array (:1112): one HDF5 file per array and wavelength
   subroutine make_output_hdf5()
     character(len=3*lcar) :: path
@@ -768,7 +857,7 @@ contains
           else if (print_scaspe_tot) then
              call out_name(lambda_arr(i), 'scaspe_tot', path)
              call io_check(drt_io_write_array(cstr(path), cstr('scaspe_tot'), 2, d2, scaspe_tot_arr(i)%a), 'print_scaspe_tot_arr')
-             call io_check(drt_io_add_int(cstr(path), cstr('nside_sca'), int(2**max(kp_sca_arr(i), 0), c_int32_t)), 'print_scaspe_tot_arr')
+             call io_check(drt_io_add_int(cstr(path), cstr('nside_sca'), int(2**kp_sca_arr(i), c_int32_t)), 'print_scaspe_tot_arr')
           endif
           if (tot_ndir > 0) then
              allocate(tmp2(0:tot_ncell+tot_p_src-1, 0:tot_ndir-1))

@@ -12,7 +12,7 @@ import numpy as np
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "io", "libdartray_io.so")
 EXPORTS = ["drt_io_last_error", "drt_io_write_main_grid", "drt_io_main_grid_size", "drt_io_read_main_grid",
            "drt_io_write_lambda_grid", "drt_io_read_lambda_grid", "drt_io_write_array", "drt_io_read_array",
-           "drt_io_add_int", "drt_io_read_int", "drt_io_filename", "drt_io_lambda_grid_filename"]
+           "drt_io_add_int", "drt_io_read_int", "drt_io_filename", "drt_io_lambda_grid_filename", "drt_io_array_dims"]
 _lib = None
 
 
@@ -141,7 +141,7 @@ def write_outputs(gpu, label: str, lambdas, out_dir: str, stage: str) -> None:
         else:
             p = j(filename(label, lambdas[il], "scaspe_tot"))
             write_array(p, "scaspe_tot", [npix, N], gpu.scaspe_tot(il))
-            add_int(p, "nside_sca", 2 ** max(int(gpu.kp[il]), 0))
+            add_int(p, "nside_sca", 2 ** int(gpu.kp[il]) if gpu.kp[il] >= 0 else 0)   # integer 2**kp_sca_arr: 0 for isotropic (kp = -1), io_routines.f90:1594
         if ndir:
             write_array(j(filename(label, lambdas[il], "i_obs_part2" if part2 else "i_obs")), "i_obs", [N + nsrc, ndir],
                         io[:, :, il])
@@ -151,7 +151,8 @@ def write_outputs(gpu, label: str, lambdas, out_dir: str, stage: str) -> None:
 
 
 def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_lambda_grid: bool = True, iref: int = 0,
-                           restore_file_mpi: bool = False) -> str:
+                           restore_file_mpi: bool = False, rt_algorithm: str = "main", label_i_obs: str = "",
+                           input_name: str = "input.in", dir_out_name: str = "dir_out.dat", only_direct_rt: bool = False) -> str:
     """Write `case` (grids.Case) as the set of files the reference's main programs read (and
     dart-ray_amd/fortran/dartray_gpu_main reads): <root>/GRIDS/ with the HDF5 main grid, one lambda grid per
     wavelength, the wavelength list, dir_out and point-source files, an effective-opacity table in the layout
@@ -161,7 +162,9 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_l
     kext(lambda)/kext(lambda_ref) from the opacity table (scale_dens_arr, rt_routines.f90:5018), which needs a case whose
     dens columns are multiples of each other and which has no diffuse stellar emission.
     restore_file_mpi: the run may start from the part-1 / part-2 files of an earlier run found in <root>/RUNS
-    (check_files, io_routines.f90:893)."""
+    (check_files, io_routines.f90:893).
+    rt_algorithm = 'i_obs' (with label_i_obs, another input_name and dir_out_name in the same root): the input of a
+    dartray_i_obs run on the scaspe_tot files a main run left in <root>/RUNS."""
     lambdas = [float(x) for x in lambdas]
     L = case.lnum
     assert len(lambdas) == L and all(b > a for a, b in zip(lambdas, lambdas[1:]))
@@ -184,7 +187,7 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_l
             f.write(f"{lam!r}\n")
     ndir, nsrc = case.dir_out.shape[0], case.p_src_pos.shape[0]
     if ndir:
-        with open(os.path.join(gdir, "dir_out.dat"), "w") as f:
+        with open(os.path.join(gdir, dir_out_name), "w") as f:
             f.write("theta phi [rad]\n")
             for th, ph in case.dir_out:
                 f.write(f"{float(th)!r} {float(ph)!r}\n")
@@ -209,12 +212,12 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_l
     ms = t.modelsize
     frac = [[float(v) for v in row] for row in (wc + ms / 2.0) / ms]  # set_walls maps fractions of modelsize to model coordinates
     fl = lambda b: ".TRUE." if b else ".FALSE."
-    inp = os.path.join(root, "input.in")
+    inp = os.path.join(root, input_name)
     with open(inp, "w") as f:
         f.write("&dartray_input_strings\n"
                 f"label_model_lambda_grid = '{label}',\nlabel_model_out = '{label}',\ngrid_file = 'grid_{label}.h5',\n"
-                "file_dir_out = 'dir_out.dat',\nfile_p_src = 'pos_point_sources.dat',\nfile_param_src = 'param_point_sources.dat',\n"
-                f"file_lambda_list = 'lambda_list.dat',\ndir_runs = '{rdir}',\ndir_grid = '{gdir}/',\nrt_algorithm = 'main',\n"
+                f"file_dir_out = '{dir_out_name}',\nfile_p_src = 'pos_point_sources.dat'," f"\nfile_param_src = 'param_point_sources.dat',\n"
+                f"file_lambda_list = 'lambda_list.dat',\ndir_runs = '{rdir}',\ndir_grid = '{gdir}/',\nrt_algorithm = '{rt_algorithm}',\n" + (f"label_model_out_i_obs = '{label_i_obs}',\n" if label_i_obs else "") + f""
                 f"units_lambda = 'um',\ndust_model = 'TRUST',\nfile_av_opacities = '{gdir}/opacities_Effective.dat',\n"
                 "units_csize = 'pc',\nunits_luminosity = 'erg/s/Hz',\ndust_heating_type = 'eff'\n/\n")
         f.write("&dartray_input_var\n"
@@ -226,7 +229,7 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_l
         f.write("&dartray_input_logical\n"
                 f"use_lambda_grid = {fl(use_lambda_grid)},\nuse_dir_out = {fl(ndir > 0)},\nuse_p_src = {fl(nsrc > 0)},\nprint_output_part1 = .TRUE.,\n"
                 "print_output_part2 = .TRUE.,\nprint_scaspe_part2 = .TRUE.,\nprint_scaspe_tot = .TRUE.,\nprint_sed = .TRUE.,\n"
-                f"input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\nrestore_file_mpi = {fl(restore_file_mpi)},\n"
+                f"input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\nrestore_file_mpi = {fl(restore_file_mpi)},\nonly_direct_rt = {fl(only_direct_rt)},\n"
                 f"x_wall_on = {fl(case.wall_on[0])},\ny_wall_on = {fl(case.wall_on[1])},\nz_wall_on = {fl(case.wall_on[2])},\n"
                 f"limit_scattering_iterations = {fl(case.max_sca_iterations >= 0)}\n/\n")
     return inp

@@ -202,6 +202,27 @@ extern "C" int drt_io_read_array(const char* path, const char* dsetname, int ran
     return read_dset(f.id, dsetname, H5T_NATIVE_DOUBLE, rank, fdims, data);
 }
 
+// extent of a dataset in Fortran order (find_out_tot_ndir_scaspe :2566-2651 asks the scaspe_tot files of an earlier run)
+extern "C" int drt_io_array_dims(const char* path, const char* dsetname, int rank, int64_t* fdims)
+{
+    if (!path || !dsetname || rank < 1 || rank > 4 || !fdims) return fail(DRT_IO_E_ARG, "drt_io_array_dims: bad argument");
+    Quiet q;
+    File f;
+    f.id = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f.id < 0) return fail(DRT_IO_E_OPEN, "file not found: '%s'", path);
+    hid_t ds = H5Dopen2(f.id, dsetname, H5P_DEFAULT);
+    if (ds < 0) return fail(DRT_IO_E_DATASET, "dataset '%s' not found", dsetname);
+    hid_t sp = H5Dget_space(ds);
+    const int r = H5Sget_simple_extent_ndims(sp);
+    hsize_t got[8] = {0};
+    if (r == rank) H5Sget_simple_extent_dims(sp, got, nullptr);
+    H5Sclose(sp);
+    H5Dclose(ds);
+    if (r != rank) return fail(DRT_IO_E_DATASET, "dataset '%s' has rank %d, expected %d", dsetname, r, rank);
+    for (int i = 0; i < rank; i++) fdims[i] = (int64_t)got[rank - 1 - i];
+    return DRT_IO_OK;
+}
+
 // add_info_big_array (:1180-1240) for the integer 'nside_sca'
 extern "C" int drt_io_add_int(const char* path, const char* dsetname, int32_t value)
 {

@@ -48,6 +48,8 @@ int drt_io_read_lambda_grid(const char* path, int32_t tot_ncell, double* dens, d
  * (N + nsrc, ndir); sed_arr, sed_arr_dir (lnum, ndir); lum_lost [lnum]; psel_av_arr. `fdims` in Fortran order. */
 int drt_io_write_array(const char* path, const char* dsetname, int rank, const int64_t* fdims, const double* data);
 int drt_io_read_array(const char* path, const char* dsetname, int rank, const int64_t* fdims, double* data);
+/* extent of a dataset, Fortran order (find_out_tot_ndir_scaspe, io_routines.f90:2566) */
+int drt_io_array_dims(const char* path, const char* dsetname, int rank, int64_t* fdims);
 /* extra int32 [1] dataset appended to an existing file (nside_sca of the scaspe_tot files) */
 int drt_io_add_int(const char* path, const char* dsetname, int32_t value);
 int drt_io_read_int(const char* path, const char* dsetname, int32_t* value);

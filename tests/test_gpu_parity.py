@@ -465,6 +465,60 @@ def test_i_obs_algorithm_matches_reference(name, golden, pkg):
     g.close()
 
 
+def test_fortran_main_runs_the_i_obs_algorithm_on_the_files_of_a_main_run(pkg, tmp_path):
+    """rt_algorithm = 'i_obs' in dartray_gpu_main (the reference's dartray_i_obs.f90 / dartray_hub.f90:125-168): a main run
+    leaves its scaspe_tot files (print_scaspe_tot); a second run with other observer directions and
+    label_model_out_i_obs reads their HEALPix rows back (more rows per cell in the file than this run has: the main
+    run's own directions), runs the three observer passes and writes 'grid_<label>_..._int.h5' (reset_filenames). Its
+    arrays must equal what the same sequence gives through the C ABI (checked against the reference's fixture in
+    test_i_obs_algorithm_matches_reference)."""
+    import copy
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "fortran", "dartray_gpu_main")
+    if not os.path.exists(exe) or not os.path.exists(pkg.io.LIB_PATH):
+        pytest.skip("Fortran main program / HDF5 library not built")
+    idx = [8, 14, 27]       # HG with 55 and 19 slots and an isotropic wavelength (nside_sca 2, 1, 0 in the files)
+    lambdas = [float(pkg.grids.TRUSTI_TABLE[i, 0]) for i in idx]
+    case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=2, wavelengths=idx, max_sca_iterations=2)
+    root = str(tmp_path)
+    inp = pkg.io.write_reference_inputs(case, lambdas, root, label="slab")
+    out = subprocess.run([exe, inp], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    # other directions, fewer of them than the main run had
+    new_dirs = np.array([[0.3 + 0.5 * th, 0.4 + 0.5 * ph] for th, ph in case.dir_out[:3]])
+    case_b = copy.copy(case)
+    case_b.dir_out = new_dirs
+    inp_b = pkg.io.write_reference_inputs(case_b, lambdas, root, label="slab", rt_algorithm="i_obs", label_i_obs="newdirs",
+                                          input_name="input_iobs.in", dir_out_name="dir_out_iobs.dat")
+    out = subprocess.run([exe, inp_b], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "i_obs algorithm" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    # the same through the C ABI
+    main = pkg.DartRayGPU(case)
+    main.run_all(31)
+    tot = [main.scaspe_tot(il) for il in range(main.L)]
+    main.close()
+    g = pkg.DartRayGPU(case_b)
+    g.set_algorithm("i_obs")
+    g.rt_prepare("start"); g.rt_prepare("prep_part2")
+    for il in range(g.L):
+        t = np.zeros((g.N, g.npix[il]))
+        t[:, :g.npix_hp[il]] = tot[il][:, :g.npix_hp[il]]
+        g.set_array("scaspe_tot", t, il)
+    g.rt_loop_iobs("i_obs_dir_src"); g.rt_loop_iobs("i_obs_dir_cell")
+    io_dir, sed_dir = g.i_obs.copy(), g.sed().copy()
+    g.rt_prepare("i_obs"); g.rt_loop_iobs("i_obs")
+    N, nsrc, ndir = g.N, g.nsrc, 3
+    f = lambda lam, what: os.path.join(root, "RUNS", pkg.io.filename("newdirs", lam, what, "_int"))
+    for il, lam in enumerate(lambdas):
+        assert relmax(pkg.io.read_array(f(lam, "i_obs"), "i_obs", [N + nsrc, ndir]), g.i_obs[:, :, il]) <= RTOL, il
+        assert relmax(pkg.io.read_array(f(lam, "i_obs_part2"), "i_obs", [N + nsrc, ndir]), io_dir[:, :, il]) <= RTOL, il
+    assert relmax(pkg.io.read_array(f(-1.0, "sed"), "sed_arr", [g.L, ndir]), g.sed()) <= 1e-9
+    assert relmax(pkg.io.read_array(f(-1.0, "sed_dir"), "sed_arr_dir", [g.L, ndir]), sed_dir) <= 1e-9
+    assert float((g.i_obs - io_dir).max()) > 0      # there is scattered light in it
+    g.close()
+
+
 @pytest.mark.parametrize("mapping", ["ray_major", "lane_per_wavelength"])
 def test_more_than_32_wavelengths_match_the_oracle(mapping, pkg, tmp_path, monkeypatch):
     """40 wavelengths per ray (the 32 of the TRUST-I list and eight of them again): the <64> instantiations of both
@@ -536,7 +590,7 @@ def test_fortran_main_on_reference_style_inputs(pkg, tmp_path):
     for il, lam in enumerate(lambdas):
         assert relmax(pkg.io.read_array(f(lam, "ufield"), "u_final", [N]), g.u_final[:, il]) <= RTOL
         assert relmax(pkg.io.read_array(f(lam, "scaspe_tot"), "scaspe_tot", [g.npix[il], N]), g.scaspe_tot(il)) <= RTOL
-        assert pkg.io.read_int(f(lam, "scaspe_tot"), "nside_sca") == 2 ** max(g.kp[il], 0)
+        assert pkg.io.read_int(f(lam, "scaspe_tot"), "nside_sca") == (2 ** g.kp[il] if g.kp[il] >= 0 else 0)   # Fortran integer 2**kp
         assert relmax(pkg.io.read_array(f(lam, "i_obs"), "i_obs", [N + nsrc, ndir]), g.i_obs[:, :, il]) <= RTOL
         assert os.path.exists(f(lam, "u_fest_part1")) and os.path.exists(f(lam, "ufield_part2")) and os.path.exists(f(lam, "scaspe_part2"))
     assert relmax(pkg.io.read_array(f(-1.0, "lum_lost"), "lum_lost", [g.L]), g.lum_lost) <= 1e-7
