@@ -174,6 +174,7 @@ typedef struct {
     rlist high, low, ext;
     int no_ray;
     orc_counters cnt;
+    int ipsel_av; double psel_av; /* rays of the running source that ended, sum of their paths (rt_routines.f90:71-72, 122-123) */
     int error;
 } tstate;
 
@@ -205,6 +206,7 @@ struct orc_ctx {
     int iterations, cnflag, rt_type;
     int np, id, nthreads;
     orc_counters cnt;
+    double *psel_av_last; /* [N + nsrc]: psel_av of every source of the last rt_loop (what rt_routines.f90:1456-1465 stores) */
     int error;
     FILE *trace; /* developer aid: ORC_TRACE=<file> logs every ray launch */
 };
@@ -407,6 +409,7 @@ static void finish_setup(orc_ctx *c)
     c->lum_lost_prev = (double *)calloc(c->L, sizeof(double));
     c->tot_rad_en = (double *)calloc(c->L, sizeof(double));
     c->i_obs = (double *)calloc((size_t)(c->ndir > 0 ? c->ndir : 1) * (c->N + c->nsrc) * c->L, sizeof(double));
+    c->psel_av_last = (double *)calloc((size_t)(c->N + c->nsrc), sizeof(double));
     c->scaspe = (double **)calloc(c->L, sizeof(double *));
     c->scaspe_tot = (double **)calloc(c->L, sizeof(double *));
     c->scaspe_prev = (double **)calloc(c->L, sizeof(double *));
@@ -523,7 +526,7 @@ void orc_destroy(orc_ctx *c)
     free2(c->sin_theta_sca, c->nuniq); free2(c->cos_theta_sca, c->nuniq);
     free2(c->sin_phi_sca, c->nuniq); free2(c->cos_phi_sca, c->nuniq);
     free(c->u_fest); free(c->u_final); free(c->lumcell); free(c->lum_lost); free(c->lum_lost_prev);
-    free(c->tot_rad_en); free(c->i_obs);
+    free(c->tot_rad_en); free(c->i_obs); free(c->psel_av_last);
     free2(c->scaspe, c->L); free2(c->scaspe_tot, c->L); free2(c->scaspe_prev, c->L);
     if (c->trace) fclose(c->trace);
     free(c);
@@ -532,6 +535,8 @@ void orc_destroy(orc_ctx *c)
 void orc_set_parallel(orc_ctx *c, int np, int id, int nthreads) { c->np = np; c->id = id; c->nthreads = nthreads < 1 ? 1 : nthreads; }
 /* rt_algorithm_ID (rt_routines.f90:232-250): 0 = rta_main, 1 = rta_i_obs - the only place where the path looks at it is the
  * source luminosity of rt_loop_iobs(rtt_i_obs), rt_routines.f90:1538-1548 */
+/* psel_av of every source (cell index, or N + point-source index) of the last rt_loop; 0 where no ray ended */
+const double *orc_psel_av(const orc_ctx *c) { return c->psel_av_last; }
 void orc_set_algorithm(orc_ctx *c, int rta) { c->rta_i_obs = (rta == 1); }
 /* new observer directions (dartray_i_obs reads another file_dir_out than the main run): theta[ndir] then phi[ndir]; i_obs is zeroed
  * like create_i_obs does (rt_routines.f90:2970-2980) */
@@ -1018,6 +1023,7 @@ static void ray_tracing(orc_ctx *c, tstate *t, int nc, double al, double dl, int
             add_to_high(t, dl, al, t->nside, prev, isel_old, dplane_ray, t->lum_tmp, cc, RAY_HIGH);
             return;
         } else if (ray_status == RAS_GONE) {
+            t->ipsel_av++; t->psel_av += psel;   /* :1746-1748 */
             return;
         } else if (ray_status == RAS_GO_LOW) {
             for (int il = 0; il < L; il++) t->lum_tmp[il] = I[il] * norm;
@@ -1036,6 +1042,7 @@ static void ray_tracing(orc_ctx *c, tstate *t, int nc, double al, double dl, int
                     if (k == 0) break;
                 }
                 if (k != 0) { /* leaving the model */
+                    t->ipsel_av++; t->psel_av += psel;   /* :1792-1793 */
                     if (rt == ORC_RTT_I_OBS_DIR_CELL || rt == ORC_RTT_I_OBS_DIR_SRC || rt == ORC_RTT_I_OBS)
                         for (int il = 0; il < L; il++) t->i_obs_temp[il] = I[il];
                     return;
@@ -1150,6 +1157,7 @@ void orc_rt_loop(orc_ctx *c, int rt_type)
     c->rt_type = rt_type;
     const int L = c->L;
     int nim = c->N / c->np + 1;
+    memset(c->psel_av_last, 0, (size_t)(c->N + c->nsrc) * sizeof(double));
 #ifdef _OPENMP
 #pragma omp parallel num_threads(c->nthreads)
 #endif
@@ -1176,7 +1184,12 @@ void orc_rt_loop(orc_ctx *c, int rt_type)
             if (rt_type == ORC_RTT_SCATT)
                 for (int il = 0; il < L; il++)
                     memcpy(t.scaspe_temp[il], c->scaspe_prev[il] + (size_t)i * c->npix_arr[il], c->npix_arr[il] * sizeof(double));
+            t.ipsel_av = 0; t.psel_av = 0;   /* :1020-1021 */
             main_dir_loop(c, &t, i, t.src_lum);
+            {   /* :1456-1465 (the reference stores it for the dir and scattering stages when print_psel_av) */
+                const int sid = (rt_type == ORC_RTT_PRECALC_SRC || rt_type == ORC_RTT_DIR_SRC) ? c->N + c->src_cell[i] : i;
+                c->psel_av_last[sid] = t.ipsel_av ? t.psel_av / t.ipsel_av : 0.0;
+            }
         }
         merge_counters(c, &t);
         ts_free(c, &t);

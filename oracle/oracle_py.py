@@ -68,6 +68,8 @@ def lib():
         L.orc_sed.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.orc_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.orc_set_algorithm.argtypes = [C.c_void_p, C.c_int]
+        L.orc_psel_av.argtypes = [C.c_void_p]
+        L.orc_psel_av.restype = C.POINTER(C.c_double)
         L.orc_calc_total_luminosity.argtypes = [C.c_void_p]
         L.orc_set_dir_out.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.orc_reset_counters.argtypes = [C.c_void_p]
@@ -114,6 +116,11 @@ class Oracle:
         d = np.ascontiguousarray(np.asarray(dir_out, dtype=np.float64).T)   # theta[ndir] then phi[ndir]
         assert d.shape == (2, self.ndir)
         self.L_.orc_set_dir_out(self.h, d.ctypes.data_as(C.POINTER(C.c_double)))
+
+    @property
+    def psel_av(self) -> np.ndarray:
+        """psel_av of every source of the last rt_loop ([N + nsrc], rt_routines.f90:1456-1465)."""
+        return np.ctypeslib.as_array(self.L_.orc_psel_av(self.h), shape=(self.N + self.nsrc,)).copy()
 
     def calc_total_luminosity(self): self.L_.orc_calc_total_luminosity(self.h)
 

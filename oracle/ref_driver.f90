@@ -10,6 +10,7 @@
 !>
 !> usage: ref_driver <case.bin> <out-prefix> [stages]
 !>   stages: bitmask, 1=precalc 2=direct 4=iobs-direct 8=scattering 16=iobs-scatt (default 31),
+!>           64 = print_psel_av: the average path of every source's rays per stage, written to "<prefix>.psel"
 !>           32 = afterwards the i_obs algorithm (dartray_i_obs) for other observer directions, written to "<prefix>.iobs"
 program ref_driver
   use smooth_grid_routines
@@ -95,7 +96,7 @@ program ref_driver
   ! input_initialize / check_input defaults that steer the path (io_routines.f90:2654-2742, 3187-3190)
   rt_algorithm = 'main'; rt_algorithm_ID = rta_main
   no_communications = .TRUE.; sequential_scattering = .TRUE.
-  print_psel_av = .FALSE.; print_scaspe_tot = .FALSE.; test_run = .FALSE.; only_direct_rt = .FALSE.
+  print_psel_av = (iand(stages,64) /= 0); print_scaspe_tot = .FALSE.; test_run = .FALSE.; only_direct_rt = .FALSE.
   use_lambda_grid = .FALSE.
   limit_scattering_iterations = (max_it >= 0); max_sca_iterations = max_it
   lnum_maps = 0
@@ -209,6 +210,7 @@ program ref_driver
         enddo
         call calc_total_luminosity_sca
         if (cnflag) exit
+        call expand_psel_av_arr                       ! rt_prepare, dartray_hub.f90:450 (returns unless print_psel_av)
         call rt_loop
         call drv_rt_mpi
      enddo
@@ -267,6 +269,13 @@ program ref_driver
   endif
   write(uo) t_pre, t_dir, t_sca, t_iobs
   close(uo)
+  if (print_psel_av) then
+     ! psel_av_arr(0, 0:iterations, 0:tot_ncell+tot_p_src-1) (rt_routines.f90:1456-1465, 3219-3290)
+     open(newunit=un, file=trim(fout)//'.psel', access='stream', form='unformatted', status='replace')
+     write(un) int(z'44524F33', kind=int32), tot_ncell, nsrc, int(size(psel_av_arr,2), kind=int32)
+     write(un) psel_av_arr
+     close(un)
+  endif
   if (main_prc) print '(a,4f10.3)', 'ref_driver timings pre/dir/sca/iobs [s]: ', t_pre, t_dir, t_sca, t_iobs
 
   call mpi_finalize(ierr)

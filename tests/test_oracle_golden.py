@@ -85,6 +85,31 @@ def test_oracle_i_obs_algorithm_matches_reference(name, golden):
     o.close()
 
 
+@pytest.mark.parametrize("name", ["cube65", "blobB"])
+def test_oracle_psel_av_matches_reference(name, golden):
+    """psel_av_arr (print_psel_av, rt_routines.f90:1456-1465): the average path of the rays of every source that ended
+    (absorbed below en_lim, wall, left the model), per direct-light stage and scattering iteration. Fixture from the
+    unmodified reference modules (oracle/ref_driver.f90 stage 64, oracle/make_golden_psel.py)."""
+    import os
+    z, path = golden(name)
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_pselav.npz"))["psel_av"]
+    hdr = np.frombuffer(z["case_bin"][:64].tobytes(), dtype=np.int32)
+    nsrc, ndir = int(hdr[6]), int(hdr[7])
+    o = op.Oracle(path, nsrc=nsrc, ndir=ndir)
+    o.rt_loop("precalc_cell"); o.rt_loop("precalc_src")
+    o.rt_loop("dir_cell"); row = o.psel_av
+    o.rt_loop("dir_src"); row = row + o.psel_av       # cells and point sources write different entries of row 0
+    o.rt_mpi("dir_src")
+    rows = [row]
+    while not o.scatt_prepare():
+        o.rt_loop("scatt"); rows.append(o.psel_av); o.rt_mpi("scatt")
+    got = np.array(rows)
+    assert got.shape == ref.shape
+    assert np.array_equal(got > 0, ref > 0)
+    assert relmax(got, ref) <= 1e-12
+    o.close()
+
+
 def test_healpix_roundtrip():
     """ang2pix_nest(pix2ang_nest(p)) == p for every pixel, nside <= 64 (healpix_routines.f90:30,238)."""
     import ctypes as C
