@@ -108,6 +108,8 @@ struct drt_ctx {
     std::vector<double> src_pred_h, cost_lum_h;
     int cost_kind = -1;
     int algorithm = 0;  // DRT_RTA_MAIN / DRT_RTA_I_OBS (drt_set_algorithm)
+    bool psel_av = false;  // print_psel_av (drt_set_psel_av)
+    double *d_psel_sum = nullptr, *d_psel_cnt = nullptr;  // [N + nsrc] each
     bool cost_synced = false;  // np_mpi > 1: d_src_cost has been summed over the ranks since the launch that measured it
     std::vector<double*> d_scaspe, d_scaspe_prev, d_scaspe_tot, d_tab;
     DevProblem* d_prob = nullptr;
@@ -220,7 +222,7 @@ extern "C" int drt_destroy(drt_ctx* c)
     free_fields(c);
     void* ptrs[] = {c->d_nbr, c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
                     c->d_u_final, c->d_lumcell, c->d_p_src_pos, c->d_p_src_lum, c->d_dir_out, c->d_lum_lost, c->d_lum_lost_prev,
-                    c->d_i_obs, c->d_tot, c->d_src_cost, c->d_heavy, c->d_deep, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter,
+                    c->d_i_obs, c->d_tot, c->d_src_cost, c->d_heavy, c->d_deep, c->d_psel_sum, c->d_psel_cnt, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter,
                     c->d_bak_lost, c->d_bak_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
@@ -1078,6 +1080,14 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
     a.task_first = 0; a.task_stride = 1;
     a.heavy = nullptr; a.n_heavy = 0; a.record_cost = cell_stage ? 1 : 0;
+    a.psel_sum = nullptr; a.psel_cnt = nullptr;
+    if (c->psel_av) {
+        if (!c->ray_major) return fail(c, DRT_E_ARG, "psel_av is kept by the ray-major kernel only (DRT_RAY_MAJOR=0 is set)");
+        const size_t M = (size_t)c->N + c->nsrc;
+        if ((rc = dev_zero(c, &c->d_psel_sum, M))) return rc;
+        if ((rc = dev_zero(c, &c->d_psel_cnt, M))) return rc;
+        a.psel_sum = c->d_psel_sum; a.psel_cnt = c->d_psel_cnt;
+    }
     // Phase window (trace_items_w): 1.5 cell sizes where deposits dominate; off where a source launches few rays (the
     // work per source of the previous call of this stage, like the sectors per task) and the emptier steps cost more
     // than the merged atomics save. DRT_PHASE_WINDOW overrides.
@@ -1196,6 +1206,10 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // few, deep sources; the sector tasks of phase 1 are dealt round the ranks
         for (int max_blocks = c->waves / 4;;) {
             if ((rc = copy_state(true))) return rc;
+            if (a.psel_sum) {  // not in the snapshot: an undone attempt must not leave its rays in the sums
+                HIPCHK(c, hipMemsetAsync(c->d_psel_sum, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
+                HIPCHK(c, hipMemsetAsync(c->d_psel_cnt, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
+            }
             HIPCHK(c, hipEventRecord(c->ev0, 0));
             bool ovf = false, fewer = false;
             if ((rc = subtree(c->d_src_list, (int)list.size(), c->par.id_mpi, c->par.np_mpi, max_blocks, ovf, fewer))) return rc;
@@ -1269,6 +1283,10 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             c->cnt.heavy_tasks = (int64_t)heavy.size(); c->cnt.deep_sources = (int64_t)deep.size();
             if ((rc = copy_state(true))) return rc;
             HIPCHK(c, hipMemsetAsync(c->d_src_cost, 0, (size_t)c->N * sizeof(double), 0));
+            if (a.psel_sum) {
+                HIPCHK(c, hipMemsetAsync(c->d_psel_sum, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
+                HIPCHK(c, hipMemsetAsync(c->d_psel_cnt, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
+            }
             HIPCHK(c, hipEventRecord(c->ev0, 0));
             bool ovf = false, fewer = false;
             if (!deep.empty()) {
@@ -1444,7 +1462,19 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
     // every rank's next deal (build_src_list)
     if ((rc = allreduce_sum(c, c->d_src_cost, (size_t)c->N))) return rc;
     c->cost_synced = true;
+    if (c->psel_av && c->d_psel_sum) {  // reduce_psel_av_arr (io_routines.f90:3859-3881); sums and counts, a source's tasks may be spread over ranks here
+        if ((rc = allreduce_sum(c, c->d_psel_sum, (size_t)c->N + c->nsrc))) return rc;
+        if ((rc = allreduce_sum(c, c->d_psel_cnt, (size_t)c->N + c->nsrc))) return rc;
+    }
     HIPCHK(c, hipDeviceSynchronize());
+    return DRT_OK;
+}
+
+// print_psel_av (rt_routines.f90:269): keep, for every rt_loop, sum and number of the paths of the rays of each source that ended
+extern "C" int drt_set_psel_av(drt_ctx* c, int32_t on)
+{
+    if (!c) return DRT_E_ARG;
+    c->psel_av = on != 0;
     return DRT_OK;
 }
 
@@ -1480,6 +1510,8 @@ static int field_ptr(drt_ctx* c, int which, int il, double** d, size_t* n, size_
     case DRT_A_LUM_LOST: *d = c->d_lum_lost; *n = (size_t)c->L; break;
     case DRT_A_LUM_LOST_PREV: *d = c->d_lum_lost_prev; *n = (size_t)c->L; break;
     case DRT_A_SRC_COST: *d = c->d_src_cost; *n = (size_t)c->N; break;
+    case DRT_A_PSEL_SUM: *d = c->d_psel_sum; *n = (size_t)c->N + c->nsrc; break;
+    case DRT_A_PSEL_CNT: *d = c->d_psel_cnt; *n = (size_t)c->N + c->nsrc; break;
     case DRT_A_I_OBS: *d = c->d_i_obs; *n = (size_t)c->ndir * (c->N + c->nsrc) * c->L; break;
     case DRT_A_SCASPE: case DRT_A_SCASPE_TOT: case DRT_A_SCASPE_PREV: {
         if (il < 0 || il >= c->L) return fail(c, DRT_E_ARG, "wavelength index %d out of range", il);
@@ -1502,6 +1534,16 @@ extern "C" int drt_get_array(drt_ctx* c, int32_t which, int32_t il, double* host
     if (which == DRT_A_TOT_RAD_EN) {
         if (count != (size_t)c->L || c->tot_rad_en.size() != count) return fail(c, DRT_E_ARG, "tot_rad_en: count mismatch");
         memcpy(host, c->tot_rad_en.data(), count * sizeof(double));
+        return DRT_OK;
+    }
+    if (which == DRT_A_PSEL_AV) {  // psel_av of every source of the last rt_loop (rt_routines.f90:1459); 0 where no ray ended
+        const size_t M = (size_t)c->N + c->nsrc;
+        if (!c->psel_av || !c->d_psel_sum) return fail(c, DRT_E_ARG, "psel_av: not enabled (drt_set_psel_av) or no rt_loop yet");
+        if (count != M) return fail(c, DRT_E_ARG, "psel_av: count must be tot_ncell + tot_p_src");
+        std::vector<double> s(M), n(M);
+        HIPCHK(c, hipMemcpy(s.data(), c->d_psel_sum, M * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(n.data(), c->d_psel_cnt, M * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < M; k++) host[k] = n[k] > 0 ? s[k] / n[k] : 0.0;
         return DRT_OK;
     }
     if (which == DRT_A_DENS_STARS) {

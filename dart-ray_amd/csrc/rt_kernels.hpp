@@ -40,6 +40,10 @@ struct StageArgs {
     // sectors_per_task sectors each. A task is one wave's serial work: no task may be a large part of the whole launch.
     const int2* heavy;
     int n_heavy;
+    // print_psel_av (rt_routines.f90:1456-1465): sum and number of the paths of the rays of every source that ended in this
+    // stage ([N + nsrc] each, null = off); the average is taken on the host (after the ranks' sums were added, if any)
+    double* psel_sum;
+    double* psel_cnt;
     int record_cost;    // add every task's duration to DevProblem::src_cost[cell] (cell-source stages)
     // phase-alignment window of the ray-major kernel in cell sizes (0 = every busy ray steps every time), see trace_items_w
     double phase_win;
@@ -154,6 +158,7 @@ __device__ __forceinline__ void gatomic_add(double* p, double v)
 }
 
 template <class T> struct WaveCountersT { T inter, rays, deps, sca, lamdep, uadd, uread, slots;
+    unsigned psel_n;                      // wave-uniform: rays of the running task that ended (psel_av)
     unsigned long long atom, atom_lanes;  // wave-uniform: atomic wave-instructions of the deposit loop and their active lanes
 #ifdef DRT_PROFILE
     unsigned long long t_setup, t_step, t_flush, t_park, t_next, t_commit, t_extract, t_total, n_steps, n_busy_lanes, n_groups, n_deps,

@@ -666,6 +666,16 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 const bool wh = wall_hit(P, rt, r.cc);
                 status = (alive && !wh) ? ST_GO_HIGH : ST_GONE;
             }
+            if (a.psel_sum) {
+                // psel_av (rt_routines.f90:1746-1748, 1792-1793): the path of a ray that ends here - given up (ras_gone) or
+                // leaving the model - is added to the task's sum (one LDS word per wave, no register)
+                const bool ended = go && (status == ST_GONE || (status == ST_CONT && n_found && !n_inside));
+                const unsigned long long be = __ballot(ended);
+                if (be) {
+                    wc.psel_n += (unsigned)__popcll(be);
+                    if (ended) (void)__hip_atomic_fetch_add(opq + 3 * 64 * DRT_OPQ + 64 * DRT_OPQ + 32, psel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
             TSTAMP(ts3);
             TACC(t_flush, ts2, ts3);
 
@@ -785,6 +795,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         if (P.utab[1] && P.utab_np[1] <= 63 && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
     }
     if (lane < LP) ll[lane] = 0.0;
+    if (lane == 0) opq[3 * 64 * DRT_OPQ + 64 * DRT_OPQ + 32] = 0.0;   // the task's sum of ended rays' paths (psel_av)
     // the per-lane tallies: one atomic per wave and counter
     auto flush_counters = [&]() {
         unsigned long long c8[8] = {wc.inter, wc.rays, wc.deps, wc.sca, wc.lamdep, wc.uadd, wc.uread, wc.slots};
@@ -915,6 +926,18 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
                 const double v = ll[lane];
                 if (v != 0.0) { atomicAdd(&P.lum_lost[lane], v); ll[lane] = 0.0; }
             }
+            wave_fence();
+        }
+        if (a.psel_sum) {
+            wave_fence();
+            ldouble* const ps = opq + 3 * 64 * DRT_OPQ + 64 * DRT_OPQ + 32;
+            if (lane == 0 && wc.psel_n) {
+                const int sid = (rt == RTT_PRECALC_SRC || rt == RTT_DIR_SRC) ? P.N + P.src_cell[nc] : nc;
+                atomicAdd(&a.psel_sum[sid], (double)*ps);
+                atomicAdd(&a.psel_cnt[sid], (double)wc.psel_n);
+                *ps = 0.0;
+            }
+            wc.psel_n = 0;
             wave_fence();
         }
         if (a.record_cost && lane == 0) atomicAdd(&P.src_cost[nc], (double)(__builtin_amdgcn_s_memtime() - t_task));

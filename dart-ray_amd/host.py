@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("DRT_LIB", os.path.join(CSRC, "libdartray_rt.so"))
 
 RTT = dict(start=0, precalc_cell=1, precalc_src=2, prep_part2=4, dir_cell=5, i_obs_dir_cell=6, dir_src=7,
            i_obs_dir_src=8, scatt=10, i_obs=11)
-A = dict(src_cost=13, u_fest=1, u_final=2, scaspe=3, scaspe_tot=4, scaspe_prev=5, lumcell=6, lum_lost=7, i_obs=8, dens=9,
+A = dict(src_cost=13, psel_av=14, psel_sum=15, psel_cnt=16, u_fest=1, u_final=2, scaspe=3, scaspe_tot=4, scaspe_prev=5, lumcell=6, lum_lost=7, i_obs=8, dens=9,
          dens_stars=10, tot_rad_en=11, lum_lost_prev=12)
 UNIQUE_ID_BYTES = 128
 
@@ -47,7 +47,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm", "drt_set_psel_av"]
 
 
 def build(force: bool = False) -> str:
@@ -104,6 +104,8 @@ def lib():
             L.drt_mark_cost_reduced.argtypes = [vp]
         if hasattr(L, "drt_set_algorithm"):
             L.drt_set_algorithm.argtypes = [vp, i32]
+        if hasattr(L, "drt_set_psel_av"):
+            L.drt_set_psel_av.argtypes = [vp, i32]
         if hasattr(L, "drt_deal_by_cost"):
             L.drt_deal_by_cost.argtypes = [dp, C.c_int64, i32, i32, ip]
         _lib = L
@@ -228,11 +230,18 @@ class DartRayGPU:
         rt = RTT[rt] if isinstance(rt, str) else rt
         fields = {"u_fest": self.device_tensor("u_fest"), "u_final": self.device_tensor("u_final"),
                   "src_cost": self.device_tensor("src_cost"), "src_cost_done": self.mark_cost_reduced}
+        if getattr(self, "psel_on", False):
+            fields["psel"] = [self.device_tensor("psel_sum"), self.device_tensor("psel_cnt")]
         if rt != RTT["precalc_src"]:
             fields["lum_lost"] = self.device_tensor("lum_lost")
             fields["lum_lost_prev"] = self.device_tensor("lum_lost_prev")
             fields["scaspe"] = [self.device_tensor("scaspe", il) for il in range(self.L)]
         return fields
+
+    def set_psel_av(self, on: bool = True):
+        """print_psel_av: keep the average path of each source's rays per stage (get_array('psel_av'))."""
+        self._chk(self.L_.drt_set_psel_av(self.h, 1 if on else 0))
+        self.psel_on = bool(on)
 
     def set_algorithm(self, name: str):
         """'main' or 'i_obs' (drt_set_algorithm)."""
@@ -285,7 +294,7 @@ class DartRayGPU:
     def _count(self, which, il):
         NL = self.N * self.L
         return {"u_fest": NL, "u_final": NL, "lumcell": NL, "dens": NL, "dens_stars": NL, "lum_lost": self.L,
-                "tot_rad_en": self.L, "lum_lost_prev": self.L, "src_cost": self.N, "i_obs": self.ndir * (self.N + self.nsrc) * self.L,
+                "tot_rad_en": self.L, "lum_lost_prev": self.L, "src_cost": self.N, "psel_av": self.N + self.nsrc, "i_obs": self.ndir * (self.N + self.nsrc) * self.L,
                 "scaspe": None, "scaspe_tot": None, "scaspe_prev": None}[which]
 
     def get_array(self, which: str, il: int = 0) -> np.ndarray:

@@ -58,6 +58,10 @@ extern "C" {
 #define DRT_A_DENS_STARS 10 /* dens_stars_arr                                :70  */
 #define DRT_A_TOT_RAD_EN 11 /* tot_rad_en(0:lnum-1)           rt_routines.f90:33  */
 #define DRT_A_LUM_LOST_PREV 12 /* lum_lost_prev(0:lnum-1)     rt_routines.f90:133 */
+#define DRT_A_PSEL_AV 14   /* [tot_ncell+tot_p_src] psel_av of every source of the last rt_loop, rt_routines.f90:1456-1465 (get only;
+                            * needs drt_set_psel_av) */
+#define DRT_A_PSEL_SUM 15  /* its numerator and denominator on the device (drt_device_ptr: summed over the ranks in rt_mpi) */
+#define DRT_A_PSEL_CNT 16
 #define DRT_A_SRC_COST 13  /* [tot_ncell] no reference counterpart: wave cycles spent on each cell source in the last cell-source
                             * rt_loop (zero elsewhere). Steers the task order / rank shares of the next one; with np_mpi > 1 it
                             * is summed over the ranks in rt_mpi like the fields (every source is traced by exactly one rank). */
@@ -128,6 +132,9 @@ int drt_set_point_sources(drt_ctx *ctx, int32_t tot_p_src, const double *ccoord_
  * the HEALPix pixel of scaspe_tot that holds the direction (assign_src_lum, rt_routines.f90:1538-1548, 3043-3071); scaspe_tot is
  * handed over with drt_set_array(DRT_A_SCASPE_TOT) after drt_rt_prepare(rtt_prep_part2). */
 int drt_set_algorithm(drt_ctx *ctx, int32_t rta);
+/* print_psel_av (rt_routines.f90:269, 1456-1465): the average path of the rays of each source that ended in a stage, read with
+ * drt_get_array(DRT_A_PSEL_AV) after the stage's rt_loop (and rt_mpi with several ranks) */
+int drt_set_psel_av(drt_ctx *ctx, int32_t on);
 int drt_set_observers(drt_ctx *ctx, int32_t tot_ndir, const double *dir_i_out);
 
 /* ---- the three entry points + rt_prepare ---------------------------------------------------------- */

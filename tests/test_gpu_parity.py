@@ -465,6 +465,36 @@ def test_i_obs_algorithm_matches_reference(name, golden, pkg):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["cube65", "blobB"])
+def test_psel_av_matches_reference(name, golden, pkg):
+    """psel_av_arr (print_psel_av, rt_routines.f90:1456-1465): with drt_set_psel_av the library keeps, per rt_loop, the
+    average path of the rays of every source that ended (given up below en_lim or at a wall, or leaving the model) -
+    whatever way the source's sectors were cut into tasks. Fixture from the unmodified reference modules; the same
+    sources have rays, and the averages agree to the accuracy of a sum taken in another order."""
+    import os
+    z, path = golden(name)
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_pselav.npz"))["psel_av"]
+    case = pkg.grids.read_case(path, name)
+    g = pkg.DartRayGPU(case)
+    with pytest.raises(pkg.host.DartRayError):
+        g.get_array("psel_av")                    # not enabled
+    g.set_psel_av(True)
+    g.rt_prepare("start")
+    g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+    g.rt_prepare("prep_part2")
+    g.rt_loop("dir_cell"); row = g.get_array("psel_av")
+    g.rt_loop("dir_src"); row = row + g.get_array("psel_av"); g.rt_mpi("dir_src")
+    rows = [row]
+    while not g.scatt_prepare():
+        g.rt_loop("scatt"); rows.append(g.get_array("psel_av")); g.rt_mpi("scatt")
+    got = np.array(rows)
+    assert got.shape == ref.shape
+    assert np.array_equal(got > 0, ref > 0)
+    assert relmax(got, ref) <= 1e-12 and relelem(got, ref) <= 1e-10
+    assert relmax(g.u_final, z["u_final"]) <= RTOL     # and the run itself is what it was
+    g.close()
+
+
 def test_fortran_main_runs_the_i_obs_algorithm_on_the_files_of_a_main_run(pkg, tmp_path):
     """rt_algorithm = 'i_obs' in dartray_gpu_main (the reference's dartray_i_obs.f90 / dartray_hub.f90:125-168): a main run
     leaves its scaspe_tot files (print_scaspe_tot); a second run with other observer directions and
