@@ -1083,9 +1083,13 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     a.psel_sum = nullptr; a.psel_cnt = nullptr;
     if (c->psel_av) {
         if (!c->ray_major) return fail(c, DRT_E_ARG, "psel_av is kept by the ray-major kernel only (DRT_RAY_MAJOR=0 is set)");
+        // a cell stage starts from zero; the point-source stage that follows it writes its own entries [N, N + nsrc) beside the
+        // cells' (one rt_mpi reduces both, psel_av_arr(.., iterations, sid) has one row for both, rt_routines.f90:1460)
         const size_t M = (size_t)c->N + c->nsrc;
-        if ((rc = dev_zero(c, &c->d_psel_sum, M))) return rc;
-        if ((rc = dev_zero(c, &c->d_psel_cnt, M))) return rc;
+        if (cell_stage || !c->d_psel_sum) {
+            if ((rc = dev_zero(c, &c->d_psel_sum, M))) return rc;
+            if ((rc = dev_zero(c, &c->d_psel_cnt, M))) return rc;
+        }
         a.psel_sum = c->d_psel_sum; a.psel_cnt = c->d_psel_cnt;
     }
     // Phase window (trace_items_w): 1.5 cell sizes where deposits dominate; off where a source launches few rays (the
@@ -1206,9 +1210,9 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // few, deep sources; the sector tasks of phase 1 are dealt round the ranks
         for (int max_blocks = c->waves / 4;;) {
             if ((rc = copy_state(true))) return rc;
-            if (a.psel_sum) {  // not in the snapshot: an undone attempt must not leave its rays in the sums
-                HIPCHK(c, hipMemsetAsync(c->d_psel_sum, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
-                HIPCHK(c, hipMemsetAsync(c->d_psel_cnt, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
+            if (a.psel_sum && c->nsrc > 0) {  // not in the snapshot: an undone attempt must not leave its rays in the sums
+                HIPCHK(c, hipMemsetAsync(c->d_psel_sum + c->N, 0, (size_t)c->nsrc * sizeof(double), 0));
+                HIPCHK(c, hipMemsetAsync(c->d_psel_cnt + c->N, 0, (size_t)c->nsrc * sizeof(double), 0));
             }
             HIPCHK(c, hipEventRecord(c->ev0, 0));
             bool ovf = false, fewer = false;

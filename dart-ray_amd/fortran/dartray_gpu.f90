@@ -14,7 +14,7 @@ module dartray_c
 
   integer(c_int), parameter :: DRT_A_U_FEST = 1, DRT_A_U_FINAL = 2, DRT_A_SCASPE = 3, DRT_A_SCASPE_TOT = 4, &
        DRT_A_SCASPE_PREV = 5, DRT_A_LUMCELL = 6, DRT_A_LUM_LOST = 7, DRT_A_I_OBS = 8, DRT_A_DENS = 9, &
-       DRT_A_DENS_STARS = 10, DRT_A_TOT_RAD_EN = 11
+       DRT_A_DENS_STARS = 10, DRT_A_TOT_RAD_EN = 11, DRT_A_PSEL_AV = 14
 
   type, bind(C) :: drt_params
      integer(c_int32_t) :: kp_sca_max, bm_par, bm_par_sca, bm_par_max
@@ -156,6 +156,11 @@ module dartray_c
        integer(c_int32_t), intent(out) :: cells(*), count
      end function drt_get_sources
      ! multi-GPU: one rank per GPU, rt_mpi's MPI_Allreduce becomes ncclAllReduce (RCCL over xGMI) on the device buffers
+     integer(c_int) function drt_set_psel_av(ctx, on) bind(C, name='drt_set_psel_av')
+       import :: c_ptr, c_int, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: on
+     end function drt_set_psel_av
      integer(c_int) function drt_set_algorithm(ctx, rta) bind(C, name='drt_set_algorithm')
        import :: c_ptr, c_int, c_int32_t
        type(c_ptr), value :: ctx
@@ -214,6 +219,8 @@ module dartray_state
   integer :: rt_algorithm_ID = 0                                           ! rt_routines.f90:48
   integer, parameter :: rta_main = 0, rta_i_obs = 1                        ! rt_routines.f90:236-238
   logical :: only_direct_rt = .FALSE., print_output_part2 = .FALSE.       ! rt_routines.f90:518, io_routines.f90:128
+  logical :: print_psel_av = .FALSE.                                       ! rt_routines.f90:270
+  real(kind=real64), allocatable :: psel_av_arr(:,:,:)                     ! smooth_grid_routines.f90:88
   ! rt_type ids, rt_routines.f90:195-217
   integer, parameter :: rtt_start = 0, rtt_precalc_cell = 1, rtt_precalc_src = 2, rtt_output_part1 = 3, &
        rtt_prep_part2 = 4, rtt_dir_cell = 5, rtt_i_obs_dir_cell = 6, rtt_dir_src = 7, rtt_i_obs_dir_src = 8, &
@@ -236,7 +243,8 @@ module dartray_hub_gpu
        accuracy, cs, dist_obs, modelsize, x_wall_on, y_wall_on, z_wall_on, cnflag, done, limit_scattering_iterations, &
        x_wall_coord, y_wall_coord, z_wall_coord, rt_type, iterations, max_sca_iterations, np_mpi, id_mpi, main_prc, &
        rtt_start, rtt_precalc_cell, rtt_precalc_src, rtt_output_part1, rtt_prep_part2, rtt_dir_cell, rtt_i_obs_dir_cell, &
-       rtt_dir_src, rtt_i_obs_dir_src, rtt_output_part2, rtt_scatt, rtt_i_obs, rt_algorithm_ID, rta_main, rta_i_obs, only_direct_rt
+       rtt_dir_src, rtt_i_obs_dir_src, rtt_output_part2, rtt_scatt, rtt_i_obs, rt_algorithm_ID, rta_main, rta_i_obs, only_direct_rt, &
+       print_psel_av, psel_av_arr
 #else
   use dartray_state
 #endif
@@ -310,6 +318,7 @@ contains
     n = int(lnum, c_size_t)*int(tot_ncell, c_size_t)
     call gpu_check(drt_set_array(gpu_ctx, DRT_A_DENS, 0, dens_arr, n), 'dens_arr')
     call gpu_check(drt_set_array(gpu_ctx, DRT_A_DENS_STARS, 0, dens_stars_arr, n), 'dens_stars_arr')
+    if (print_psel_av) call gpu_check(drt_set_psel_av(gpu_ctx, 1_c_int32_t), 'drt_set_psel_av')
   end subroutine gpu_grid_initialize
 
   !> np_mpi > 1: create the RCCL communicator rt_mpi reduces over. `id` is the 128-byte unique id that the main rank
@@ -419,6 +428,29 @@ contains
     call gpu_check(drt_rt_mpi(gpu_ctx, int(rt_type, c_int32_t)), 'rt_mpi')
   end subroutine rt_mpi
 
+  !> psel_av_arr(0, iterations, :) of the stage just reduced (rt_routines.f90:1456-1465; create_psel_av_arr / expand_psel_av_arr
+  !> :3219-3290 keep one row per scattering iteration): called after rt_mpi of the direct light and of every scattering iteration.
+  subroutine gpu_collect_psel_av()
+    real(kind=real64), allocatable :: tmp(:,:,:)
+    integer :: m, nit
+    if (.not. print_psel_av) return
+    m = tot_ncell + tot_p_src
+    if (.not. allocated(psel_av_arr)) then
+       allocate(psel_av_arr(0:0, 0:iterations, 0:m-1))
+       psel_av_arr = 0
+    else if (size(psel_av_arr, 2) < iterations + 1) then
+       nit = size(psel_av_arr, 2)
+       allocate(tmp(0:0, 0:nit-1, 0:m-1))
+       tmp = psel_av_arr
+       deallocate(psel_av_arr)
+       allocate(psel_av_arr(0:0, 0:iterations, 0:m-1))
+       psel_av_arr = 0
+       psel_av_arr(:, 0:nit-1, :) = tmp
+       deallocate(tmp)
+    endif
+    call gpu_check(drt_get_array(gpu_ctx, DRT_A_PSEL_AV, 0, psel_av_arr(0, iterations, :), int(m, c_size_t)), 'psel_av_arr')
+  end subroutine gpu_collect_psel_av
+
   !> Bring the fields a stage produced back into module state (what make_output and calc_sed read).
   subroutine gpu_sync_to_host(stage)
     integer, intent(in) :: stage
@@ -526,6 +558,7 @@ contains
        case (rtt_dir_src)
           call rt_loop
           call rt_mpi
+          call gpu_collect_psel_av
        case (rtt_i_obs_dir_cell)
           call rt_prepare
           call rt_loop_iobs
@@ -542,6 +575,7 @@ contains
              if (cnflag) exit
              call rt_loop
              call rt_mpi
+             call gpu_collect_psel_av
           enddo
        case (rtt_i_obs)
           call rt_prepare

@@ -104,7 +104,7 @@ module dartray_io_gpu
   integer :: ind_i_obs(0:max_n_input-1), ind_out_maps(0:max_n_input-1), n_dust_size_qabs(0:3), n_dust_wave_qabs, &
        n_dust_temp_cal(0:3), kp_maps, n_int_rf_bins
   logical :: print_scaspe_tot, print_output_part1, print_scaspe_part2, restore_file_mpi, &   ! print_output_part2, only_direct_rt: dartray_state
-       use_lambda_grid, use_dir_out, use_pos_obs, use_p_src, print_psel_av, sequential_scattering, print_sed, &
+       use_lambda_grid, use_dir_out, use_pos_obs, use_p_src, sequential_scattering, print_sed, &   ! print_psel_av: dartray_state
        input_av_opacities, no_communications, no_dust_rt, test_run, print_maps, print_maps_in, &
        use_stellar_library
   namelist /dartray_input_strings/ label_model_lambda_grid, label_model_out, label_model_out_i_obs, file_dir_out, &
@@ -694,6 +694,9 @@ contains
        endif
     enddo
     if (out_exists(-1.0_real64, 'lum_lost')) call stop_prc('STOP(check_files): the lum_lost output file exists already')
+    if (print_psel_av) then
+       if (out_exists(-1.0_real64, 'psel_av')) call stop_prc('STOP(check_files): the psel_av output file exists already')
+    endif
     all_there = .TRUE.
     do i = 0, lnum-1
        if (.not. out_exists(lambda_arr(i), 'ufield_part2')) all_there = .FALSE.
@@ -703,6 +706,9 @@ contains
        endif
     enddo
     if (.not. out_exists(-1.0_real64, 'lum_lost_part2')) all_there = .FALSE.
+    if (print_psel_av) then
+       if (.not. out_exists(-1.0_real64, 'psel_av_part2')) all_there = .FALSE.
+    endif
     if (all_there .and. restore_file_mpi) then
        file_restore = .TRUE.
        print *, 'Intermediate files will be restored'
@@ -748,6 +754,13 @@ contains
        d1 = lnum
        call out_name(-1.0_real64, 'lum_lost_part2', path)
        call io_check(drt_io_read_array(cstr(path), cstr('lum_lost'), 1, d1, lum_lost), 'read_lum_lost')
+       if (print_psel_av) then      ! read_psel_av_arr (io_routines.f90:1364-1379)
+          if (allocated(psel_av_arr)) deallocate(psel_av_arr)
+          allocate(psel_av_arr(0:0, 0:0, 0:tot_ncell+tot_p_src-1))
+          call out_name(-1.0_real64, 'psel_av_part2', path)
+          call io_check(drt_io_read_array(cstr(path), cstr('psel_av_arr'), 3, &
+               [1_c_int64_t, 1_c_int64_t, int(tot_ncell+tot_p_src, c_int64_t)], psel_av_arr), 'read_psel_av_arr')
+       endif
     endif
     if (file_restore_part1) then
        print *, 'restoring output part 1...'
@@ -872,6 +885,19 @@ contains
              deallocate(tmp2)
           endif
        enddo
+       if (print_psel_av .and. allocated(psel_av_arr)) then
+          ! print_psel_av_arr (io_routines.f90:1337-1361): (1, 1, sources) after the direct light, (1, iterations, sources) at the end
+          if (rt_type == rtt_output_part2) then
+             call out_name(-1.0_real64, 'psel_av_part2', path)
+             call io_check(drt_io_write_array(cstr(path), cstr('psel_av_arr'), 3, &
+                  [1_c_int64_t, 1_c_int64_t, int(tot_ncell+tot_p_src, c_int64_t)], psel_av_arr(0:0, 0:0, :)), 'print_psel_av_arr')
+          else
+             call out_name(-1.0_real64, 'psel_av', path)
+             call io_check(drt_io_write_array(cstr(path), cstr('psel_av_arr'), 3, &
+                  [1_c_int64_t, int(min(iterations, size(psel_av_arr, 2)), c_int64_t), int(tot_ncell+tot_p_src, c_int64_t)], &
+                  psel_av_arr(0:0, 0:min(iterations, size(psel_av_arr, 2))-1, :)), 'print_psel_av_arr')
+          endif
+       endif
        d1 = lnum
        if (rt_type == rtt_output_part2) then
           call out_name(-1.0_real64, 'lum_lost_part2', path)

@@ -152,7 +152,8 @@ def write_outputs(gpu, label: str, lambdas, out_dir: str, stage: str) -> None:
 
 def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_lambda_grid: bool = True, iref: int = 0,
                            restore_file_mpi: bool = False, rt_algorithm: str = "main", label_i_obs: str = "",
-                           input_name: str = "input.in", dir_out_name: str = "dir_out.dat", only_direct_rt: bool = False) -> str:
+                           input_name: str = "input.in", dir_out_name: str = "dir_out.dat", only_direct_rt: bool = False,
+                           print_psel_av: bool = False) -> str:
     """Write `case` (grids.Case) as the set of files the reference's main programs read (and
     dart-ray_amd/fortran/dartray_gpu_main reads): <root>/GRIDS/ with the HDF5 main grid, one lambda grid per
     wavelength, the wavelength list, dir_out and point-source files, an effective-opacity table in the layout
@@ -229,7 +230,7 @@ def write_reference_inputs(case, lambdas, root: str, label: str = "model", use_l
         f.write("&dartray_input_logical\n"
                 f"use_lambda_grid = {fl(use_lambda_grid)},\nuse_dir_out = {fl(ndir > 0)},\nuse_p_src = {fl(nsrc > 0)},\nprint_output_part1 = .TRUE.,\n"
                 "print_output_part2 = .TRUE.,\nprint_scaspe_part2 = .TRUE.,\nprint_scaspe_tot = .TRUE.,\nprint_sed = .TRUE.,\n"
-                f"input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\nrestore_file_mpi = {fl(restore_file_mpi)},\nonly_direct_rt = {fl(only_direct_rt)},\n"
+                f"input_av_opacities = .TRUE.,\nno_communications = .TRUE.,\nno_dust_rt = .TRUE.,\nrestore_file_mpi = {fl(restore_file_mpi)},\nonly_direct_rt = {fl(only_direct_rt)},\nprint_psel_av = {fl(print_psel_av)},\n"
                 f"x_wall_on = {fl(case.wall_on[0])},\ny_wall_on = {fl(case.wall_on[1])},\nz_wall_on = {fl(case.wall_on[2])},\n"
                 f"limit_scattering_iterations = {fl(case.max_sca_iterations >= 0)}\n/\n")
     return inp

@@ -482,9 +482,8 @@ def test_psel_av_matches_reference(name, golden, pkg):
     g.rt_prepare("start")
     g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
     g.rt_prepare("prep_part2")
-    g.rt_loop("dir_cell"); row = g.get_array("psel_av")
-    g.rt_loop("dir_src"); row = row + g.get_array("psel_av"); g.rt_mpi("dir_src")
-    rows = [row]
+    g.rt_loop("dir_cell"); g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+    rows = [g.get_array("psel_av")]     # cells and point sources of the direct light share row 0
     while not g.scatt_prepare():
         g.rt_loop("scatt"); rows.append(g.get_array("psel_av")); g.rt_mpi("scatt")
     got = np.array(rows)
@@ -492,6 +491,43 @@ def test_psel_av_matches_reference(name, golden, pkg):
     assert np.array_equal(got > 0, ref > 0)
     assert relmax(got, ref) <= 1e-12 and relelem(got, ref) <= 1e-10
     assert relmax(g.u_final, z["u_final"]) <= RTOL     # and the run itself is what it was
+    g.close()
+
+
+def test_fortran_main_prints_psel_av(pkg, tmp_path):
+    """print_psel_av = .TRUE. in dartray_gpu_main: 'grid_<label>_psel_av_part2.h5' (1, 1, sources) after the direct light and
+    'grid_<label>_psel_av.h5' (1, iterations, sources) at the end (print_psel_av_arr, io_routines.f90:1337-1361), with the
+    rows a run through the C ABI collects stage by stage."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.__file__), "fortran", "dartray_gpu_main")
+    if not os.path.exists(exe) or not os.path.exists(pkg.io.LIB_PATH):
+        pytest.skip("Fortran main program / HDF5 library not built")
+    idx = [8, 14]
+    lambdas = [float(pkg.grids.TRUSTI_TABLE[i, 0]) for i in idx]
+    case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=2, wavelengths=idx, max_sca_iterations=2)
+    root = str(tmp_path)
+    inp = pkg.io.write_reference_inputs(case, lambdas, root, label="slab", print_psel_av=True)
+    out = subprocess.run([exe, inp], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    g = pkg.DartRayGPU(case)
+    g.set_psel_av(True)
+    g.rt_prepare("start")
+    g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+    g.rt_prepare("prep_part2")
+    g.rt_loop("dir_cell"); g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+    rows = [g.get_array("psel_av")]
+    while not g.scatt_prepare():
+        g.rt_loop("scatt"); g.rt_mpi("scatt"); rows.append(g.get_array("psel_av"))
+    rows = np.array(rows)
+    M = g.N + g.nsrc
+    assert g.iterations == rows.shape[0]
+    f = lambda what: os.path.join(root, "RUNS", pkg.io.filename("slab", -1.0, what))
+    p2 = pkg.io.read_array(f("psel_av_part2"), "psel_av_arr", [1, 1, M])
+    assert relmax(p2.reshape(M), rows[0]) <= 1e-12
+    fin = pkg.io.read_array(f("psel_av"), "psel_av_arr", [1, g.iterations, M])      # C order: [M][iterations][1]
+    assert relmax(fin.reshape(M, g.iterations).T, rows) <= 1e-12
+    assert (rows[0] > 0).sum() == 1 and rows[0][g.N] > 0      # the direct light comes from the star alone
     g.close()
 
 
