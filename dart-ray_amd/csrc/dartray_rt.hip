@@ -912,9 +912,9 @@ extern "C" int drt_deal_by_cost(const double* cost, int64_t n, int32_t np, int32
 
 // ---- rt_loop ---------------------------------------------------------------------------------------------
 // The sources of one rt_loop call on this rank. Cell sources are shared among the ranks in CHUNKS of consecutive
-// emitting cells dealt round the ranks (block-cyclic; DRT_PARTITION_CHUNK cells per chunk, default 64).
-// Sums over sources commute, so every deal gives the same fields after rt_mpi; what differs is speed (measured on the
-// bench workload with 8 ranks, tools/partition_ab.py):
+// emitting cells (DRT_PARTITION_CHUNK cells per chunk, default 64), dealt by expected cost (deal_by_cost; DRT_PARTITION=cyclic
+// deals them round the ranks instead). Sums over sources commute, so every deal gives the same fields after rt_mpi; what
+// differs is speed (measured on the bench workload with 8 ranks, tools/partition_ab.py):
 //  * the reference's deal, every np-th cell (i = im*np_mpi + id_mpi, rt_routines.f90:1003-1005; DRT_PARTITION=mod),
 //    balances well but a rank's sources are no longer neighbours: they stop sharing tree, density and scaspe lines in
 //    the caches and the SUM of the ranks' times grows by 40 % at 32 wavelengths and 5.4x at one;
@@ -942,7 +942,6 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool 
         if (!iobs && !psrc && by_mod && (i % np) != id) continue;
         list.push_back(i);
     }
-    // the wave time every source took in the previous cell-source launch, summed over the ranks by rt_mpi
     // Expected cost of every source of this launch. Measured (same kind of stage, cost known): the measured wave time times
     // the ratio of the source's luminosity now and then - a source emits fewer rays as its luminosity falls from one
     // scattering iteration to the next (bench grid: the time of a source falls to 8-34 % from iteration 1 to 2, exponent 1
