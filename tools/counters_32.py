@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Developer tool: all counters of one scattering step of the bench workload."""
+import sys; import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge._load_pkg()
 case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=5, wavelengths=list(range(32)))

@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""Developer tool: per-source wave time and luminosity of the first scattering iterations of the bench grid, dumped for offline analysis."""
 import os, sys
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge._load_pkg()
 for nl in (1, 32):
@@ -20,5 +23,5 @@ for nl in (1, 32):
         g.rt_mpi("scatt")
         it += 1
     out["lvl"] = case.tree.lvl; out["ccoord"] = case.tree.ccoord; out["csize"] = case.tree.csize
-    np.savez_compressed(f"/root/repo/gpurun_out/costdump{nl}.npz", **out)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"costdump{nl}.npz"), **out)
     g.close()
