@@ -61,7 +61,12 @@ typedef ldouble* iptr_t;
 #define DRT_OPQ 4  // wavelengths whose operands (dens, aux, intensity: 3 x 64 doubles each) are staged in LDS at a time
 #endif
 // + [DRT_OPQ][64] u_final sums of the chunk's wavelengths by leader lane, + 64 ints: the leader lanes in rank order
-#define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ + 3 + 64 * DRT_OPQ + 32 + 1)
+// (one wavelength: a chunk of one)
+#define DRT_OPQ_OF(LP) ((LP) == 1 ? 1 : DRT_OPQ)
+#define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ_OF(LP) + 3 + 64 * DRT_OPQ_OF(LP) + 32 + 1)
+// waves per SIMD of an instantiation; four for one wavelength (128 registers, 5 KB of LDS per wave) was tried after the register
+// diet of round 2: 585 against 503 ms on the bench grid, 6.1 against 4.9 ms on config 1 - the loop still spills at 128
+#define DRT_WAVES_OF(LP) DRT_WIDE_WAVES
 struct HotP {
     int L;
     double tau_thin, cs, en_lim;
@@ -559,14 +564,14 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 // wavelength and lane, issued together and waited for once). gfx950 has ONE in-order counter for loads and
                 // atomics: a load issued after a wavelength's atomics waits for all of them, so fetching per wavelength
                 // drained the atomic queue eleven times per step; per chunk it is two or three.
-                constexpr int OPQ = (LP == 1) ? 1 : DRT_OPQ;  // one wavelength: nothing to chunk
+                constexpr int OPQ = DRT_OPQ_OF(LP);  // one wavelength: nothing to chunk
                 // u_final: 256 contiguous bytes per cell at 32 wavelengths. One atomic per wavelength with a lane per cell is
                 // one 64-byte request per (cell, wavelength); the sums of a chunk's wavelengths, gathered in LDS by cell and
                 // sent as ONE instruction with the lanes (cell, wavelength), are one or two requests per cell - the step runs
                 // at the request rate of the memory-side atomic unit.
                 constexpr bool UB = (LP > 1);
-                ldouble* const ubuf = opq + 3 * 64 * DRT_OPQ;                   // [OPQ][64]
-                __attribute__((address_space(3))) int* const lead_lane = (__attribute__((address_space(3))) int*)(ubuf + 64 * DRT_OPQ);
+                ldouble* const ubuf = opq + 3 * 64 * DRT_OPQ_OF(LP);                   // [OPQ][64]
+                __attribute__((address_space(3))) int* const lead_lane = (__attribute__((address_space(3))) int*)(ubuf + 64 * DRT_OPQ_OF(LP));
                 const unsigned long long Mbr = __ballot(br != 0);
                 while (lam_any) {
                     unsigned long long chunk_leaders = 0ull;
@@ -673,7 +678,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 const unsigned long long be = __ballot(ended);
                 if (be) {
                     wc.psel_n += (unsigned)__popcll(be);
-                    if (ended) (void)__hip_atomic_fetch_add(opq + 3 * 64 * DRT_OPQ + 64 * DRT_OPQ + 32, psel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ended) (void)__hip_atomic_fetch_add(opq + 3 * 64 * DRT_OPQ_OF(LP) + 64 * DRT_OPQ_OF(LP) + 32, psel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             TSTAMP(ts3);
@@ -741,7 +746,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 // the instantiation without it has no memory-table path in its deposit loop.
 // Dynamic LDS: per wave DRT_LDS_WORDS(L, LP) doubles.
 template <int LP, bool BIG>
-__global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
+__global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
 {
     extern __shared__ double lds_w[];
     const DevProblem& P = *Pp;
@@ -795,7 +800,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         if (P.utab[1] && P.utab_np[1] <= 63 && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
     }
     if (lane < LP) ll[lane] = 0.0;
-    if (lane == 0) opq[3 * 64 * DRT_OPQ + 64 * DRT_OPQ + 32] = 0.0;   // the task's sum of ended rays' paths (psel_av)
+    if (lane == 0) opq[3 * 64 * DRT_OPQ_OF(LP) + 64 * DRT_OPQ_OF(LP) + 32] = 0.0;   // the task's sum of ended rays' paths (psel_av)
     // the per-lane tallies: one atomic per wave and counter
     auto flush_counters = [&]() {
         unsigned long long c8[8] = {wc.inter, wc.rays, wc.deps, wc.sca, wc.lamdep, wc.uadd, wc.uread, wc.slots};
@@ -930,7 +935,7 @@ __global__ void __launch_bounds__(256, DRT_WIDE_WAVES) rt_stage_wide(const DevPr
         }
         if (a.psel_sum) {
             wave_fence();
-            ldouble* const ps = opq + 3 * 64 * DRT_OPQ + 64 * DRT_OPQ + 32;
+            ldouble* const ps = opq + 3 * 64 * DRT_OPQ_OF(LP) + 64 * DRT_OPQ_OF(LP) + 32;
             if (lane == 0 && wc.psel_n) {
                 const int sid = (rt == RTT_PRECALC_SRC || rt == RTT_DIR_SRC) ? P.N + P.src_cell[nc] : nc;
                 atomicAdd(&a.psel_sum[sid], (double)*ps);
