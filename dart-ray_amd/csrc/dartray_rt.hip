@@ -558,7 +558,7 @@ template <int LP> static int stage_blocks_per_cu()
     return nb;
 }
 
-static size_t wide_lds_bytes(const drt_ctx* c) { return 4ull * DRT_LDS_WORDS(c->L, c->LP) * sizeof(double); }
+static size_t wide_lds_bytes(const drt_ctx* c) { return (4ull * DRT_LDS_WORDS(c->L, c->LP) + (c->LP > 1 ? DRT_TAB_WORDS : 0)) * sizeof(double); }
 template <int LP, bool BIG> static int wide_blocks_per_cu_(drt_ctx* c)
 {
     int nb = 0;

@@ -27,7 +27,10 @@
                           // after the deposit loop had been rolled up: 2 waves + intensities in LDS 6.98 s per step, 2 waves +
                           // arena 7.2 s, 3 waves + arena 6.65 s, 4 waves + arena 7.98 s (128 registers: spills in the loop)
 #endif
-struct SlotTabs { double x0, y0, z0, x1, y1, z1; };  // unit vectors of scaspe slot `lane` of slot tables 0 and 1 (where they fit the lanes)
+// Several wavelengths: the unit vectors of tables 0 and 1 live in LDS, once per block ([2][3][64] doubles behind the waves'
+// areas; 4.34 -> 4.30 s on the bench step); one wavelength: table 0 in registers (LDS there: 501 -> 511 ms).
+struct SlotTabs { double x0, y0, z0; const __attribute__((address_space(3))) double* tabs; };
+#define DRT_TAB_WORDS (6 * 64)  // unit vectors of scaspe slot `lane` of slot tables 0 and 1 (where they fit the lanes)
 
 
 // ---- memory discipline of the wavelength loop ---------------------------------------------------------
@@ -170,7 +173,7 @@ __device__ __forceinline__ double pow_m1p5_f(double x)
 // uniform-address ds_reads (one LDS instruction per double, no VALU slot) instead of two v_readlane per double -
 // the loop is VALU-issue-bound and ten of its ~22 vector instructions per ray were readlanes.
 #define DRT_BST 64  // row length of the broadcast staging area
-template <bool BIG>
+template <bool BIG, bool TLDS>
 __device__ __forceinline__ unsigned long long flush_lambda(const DevProblem& P, unsigned long long M, unsigned long long MC, int cc, double U, const ldouble* bst,
                                              int l, const SlotTabs& T, const HotP& H, const LaneTab& LT, WideCounters& wc,
                                              unsigned long long Mbr = 0ull, ldouble* urow = nullptr)
@@ -185,7 +188,11 @@ __device__ __forceinline__ unsigned long long flush_lambda(const DevProblem& P, 
     const int reg = (tid < 0) ? -1 : (tid <= 1 && np <= 63) ? tid : 2;  // 0 / 1: register table, -1: isotropic, 2: memory table
     const unsigned long long srow0 = readlane_u64(LT.srow, l);
     const double ga = 1.0 + g * g, gb = 2.0 * g;
-    const double tx = (reg == 1) ? T.x1 : T.x0, ty = (reg == 1) ? T.y1 : T.y0, tz = (reg == 1) ? T.z1 : T.z0;
+    double tx = T.x0, ty = T.y0, tz = T.z0;
+    if constexpr (TLDS) {
+        const int toff = (reg == 1) ? 3 * 64 : 0;
+        tx = T.tabs[toff + lane]; ty = T.tabs[toff + 64 + lane]; tz = T.tabs[toff + 128 + lane];
+    }
     const bool slot_lane = lane < np;   // lanes that are scaspe slots of this wavelength (all of them below np <= 63)
     unsigned na = 0, nl = 0;            // atomic instructions and their active lanes (wave-uniform, scalar registers)
     // u_final: the sum of a cell group is handed to the group's first lane; ONE atomic instruction after the loop adds
@@ -630,7 +637,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                     __builtin_amdgcn_wave_barrier();
                                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                                    chunk_leaders |= flush_lambda<BIG>(P, M, MC, cc_s, U, bst, l, T, H, LT, wc, Mbr, UB ? ubuf + q * 64 : nullptr);
+                                    chunk_leaders |= flush_lambda<BIG, (LP > 1)>(P, M, MC, cc_s, U, bst, l, T, H, LT, wc, Mbr, UB ? ubuf + q * 64 : nullptr);
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                     __builtin_amdgcn_wave_barrier();
                                 }
@@ -793,11 +800,20 @@ __global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const Dev
     if constexpr (LP == 1) {  // one wavelength: the row of the table is the same in every lane and lives in scalar registers
         LT.g = P.g[0]; LT.ksca = P.ksca[0]; LT.np = P.npix[0]; LT.ns = P.nstride[0]; LT.tid = P.tabid[0]; LT.srow = (unsigned long long)P.scaspe[0];
     } else if (lane < P.L) { LT.g = P.g[lane]; LT.ksca = P.ksca[lane]; LT.np = P.npix[lane]; LT.ns = P.nstride[lane]; LT.tid = P.tabid[lane]; LT.srow = (unsigned long long)P.scaspe[lane]; }
-    SlotTabs T = {0, 0, 0, 0, 0, 0};
-    if (a.scatter) {
-        if (P.utab[0] && P.utab_np[0] <= 63 && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }
-        if constexpr (LP > 1)  // one wavelength has one table
-        if (P.utab[1] && P.utab_np[1] <= 63 && lane < P.utab_np[1]) { const int n = P.utab_np[1]; T.x1 = P.utab[1][lane]; T.y1 = P.utab[1][n + lane]; T.z1 = P.utab[1][2 * n + lane]; }
+    SlotTabs T = {0, 0, 0, nullptr};
+    if constexpr (LP == 1) {
+        if (a.scatter && P.utab[0] && P.utab_np[0] <= 63 && lane < P.utab_np[0]) { const int n = P.utab_np[0]; T.x0 = P.utab[0][lane]; T.y0 = P.utab[0][n + lane]; T.z0 = P.utab[0][2 * n + lane]; }
+    } else {
+        ldouble* const tabs_w = (ldouble*)lds_w + waves_per_block * DRT_LDS_WORDS(L, LP);
+        T.tabs = tabs_w;
+        if (wib == 0) {
+            for (int q = 0; q < 6; q++) tabs_w[q * 64 + lane] = 0.0;
+            if (a.scatter) {
+                if (P.utab[0] && P.utab_np[0] <= 63 && lane < P.utab_np[0]) { const int n = P.utab_np[0]; tabs_w[lane] = P.utab[0][lane]; tabs_w[64 + lane] = P.utab[0][n + lane]; tabs_w[128 + lane] = P.utab[0][2 * n + lane]; }
+                if (P.utab[1] && P.utab_np[1] <= 63 && lane < P.utab_np[1]) { const int n = P.utab_np[1]; tabs_w[192 + lane] = P.utab[1][lane]; tabs_w[256 + lane] = P.utab[1][n + lane]; tabs_w[320 + lane] = P.utab[1][2 * n + lane]; }
+            }
+        }
+        __syncthreads();
     }
     if (lane < LP) ll[lane] = 0.0;
     if (lane == 0) opq[3 * 64 * DRT_OPQ_OF(LP) + 64 * DRT_OPQ_OF(LP) + 32] = 0.0;   // the task's sum of ended rays' paths (psel_av)
