@@ -88,6 +88,20 @@ def test_missing_files_and_foreign_algorithms_are_refused(pkg, tmp_path):
     assert r.returncode != 0 and "outside the GPU path" in r.stdout and "nowhere.dat" in r.stdout
 
 
+def test_i_obs_algorithm_input_is_accepted(pkg, tmp_path):
+    """rt_algorithm = 'i_obs' (io_routines.f90:2778-2779): accepted, label_model_out_i_obs defaults to label_model_out
+    (:2898-2902) and observer directions are required; test_run stops before the GPU is touched."""
+    exe = _exe(pkg)
+    case = pkg.grids.slab_case(max_lvl=2, nlambda=2, ndir=2)
+    inp = pkg.io.write_reference_inputs(case, [0.5, 1.0], str(tmp_path), label="slab", rt_algorithm="i_obs")
+    r = subprocess.run([exe, inp, "0", "test_run"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "test_run" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    txt = open(inp).read()
+    open(inp, "w").write(txt.replace("use_dir_out = .TRUE.", "use_dir_out = .FALSE."))
+    r = subprocess.run([exe, inp, "0", "test_run"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "needs observer directions" in r.stdout
+
+
 def test_main_grid_only_needs_emission_free_main_grid(pkg, tmp_path):
     """Without lambda grids there is no spectrum for diffuse stellar emission (the reference's user routines set it):
     refused with a message instead of running with zeros."""
