@@ -792,6 +792,15 @@ static int prepare_part2(drt_ctx* c)
     return upload_problem(c);
 }
 
+// u_final sums that rode in the padding slot of the scaspe rows (rt_wide.hpp, flush_lambda) go where they belong
+__global__ void k_fold_pad(double* __restrict__ row, double* __restrict__ u_final, int N, int L, int il, int np, int ns)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double v = row[(size_t)i * ns + np];
+    if (v != 0.0) { u_final[(size_t)i * L + il] += v; row[(size_t)i * ns + np] = 0.0; }
+}
+
 static int lumcell_from(drt_ctx* c, const std::vector<double*>& arr, int all_pix, std::vector<double>& totals)
 {
     const int N = c->N, L = c->L;
@@ -1321,6 +1330,10 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         c->overflow_met = false;
     }
     HIPCHK(c, hipGetLastError());
+    if (direct && c->ray_major && c->LP > 1)
+        for (int il = 0; il < c->L; il++)
+            if (c->npix[il] < c->nstride[il] && c->npix[il] < 64)
+                hipLaunchKernelGGL(k_fold_pad, dim3((c->N + 255) / 256), dim3(256), 0, 0, c->d_scaspe[il], c->d_u_final, c->N, c->L, il, c->npix[il], c->nstride[il]);
     HIPCHK(c, hipEventRecord(c->ev1, 0));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
