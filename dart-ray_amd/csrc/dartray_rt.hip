@@ -1068,9 +1068,21 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if ((rc = build_src_list(c, rt_type, list, true))) return rc;
     const int64_t inter_before = c->cnt.intersections;  // the device counters run on until drt_reset_counters
     c->cnt.sources = (int64_t)list.size();
-    c->cnt.kernel_ms = 0; c->cnt.launches = 0; c->cnt.heavy_tasks = 0; c->cnt.deep_sources = 0;
+    c->cnt.kernel_ms = 0; c->cnt.launches = 0; c->cnt.heavy_tasks = 0; c->cnt.deep_sources = 0; c->cnt.retries = 0;
     const bool cell_stage = !(rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC);
     if (cell_stage) HIPCHK(c, hipMemset(c->d_src_cost, 0, (size_t)c->N * sizeof(double)));  // build_src_list has read the previous launch's
+    // psel_av: a cell stage starts from zero; the point-source stage that follows it writes its own entries [N, N + nsrc) beside the
+    // cells' (one rt_mpi reduces both, psel_av_arr(.., iterations, sid) has one row for both, rt_routines.f90:1460). Done BEFORE the
+    // empty-list return: a rank without sources of its own (fewer emitting cells than ranks) still takes part in rt_mpi's
+    // reduction of these arrays, with zeros and not with the previous stage's sums.
+    if (c->psel_av) {
+        if (!c->ray_major) return fail(c, DRT_E_ARG, "psel_av is kept by the ray-major kernel only (DRT_RAY_MAJOR=0 is set)");
+        const size_t M = (size_t)c->N + c->nsrc;
+        if (cell_stage || !c->d_psel_sum) {
+            if ((rc = dev_zero(c, &c->d_psel_sum, M))) return rc;
+            if ((rc = dev_zero(c, &c->d_psel_cnt, M))) return rc;
+        }
+    }
     if (list.empty()) return DRT_OK;
     if ((rc = ensure_arena(c))) return rc;
     if (c->hprob.arena != c->d_arena || c->hprob.bm_par != c->bm_par_cur) if ((rc = upload_problem(c))) return rc;
@@ -1089,17 +1101,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     a.task_first = 0; a.task_stride = 1;
     a.heavy = nullptr; a.n_heavy = 0; a.record_cost = cell_stage ? 1 : 0;
     a.psel_sum = nullptr; a.psel_cnt = nullptr;
-    if (c->psel_av) {
-        if (!c->ray_major) return fail(c, DRT_E_ARG, "psel_av is kept by the ray-major kernel only (DRT_RAY_MAJOR=0 is set)");
-        // a cell stage starts from zero; the point-source stage that follows it writes its own entries [N, N + nsrc) beside the
-        // cells' (one rt_mpi reduces both, psel_av_arr(.., iterations, sid) has one row for both, rt_routines.f90:1460)
-        const size_t M = (size_t)c->N + c->nsrc;
-        if (cell_stage || !c->d_psel_sum) {
-            if ((rc = dev_zero(c, &c->d_psel_sum, M))) return rc;
-            if ((rc = dev_zero(c, &c->d_psel_cnt, M))) return rc;
-        }
-        a.psel_sum = c->d_psel_sum; a.psel_cnt = c->d_psel_cnt;
-    }
+    if (c->psel_av) { a.psel_sum = c->d_psel_sum; a.psel_cnt = c->d_psel_cnt; }
     // Phase window (trace_items_w): 1.5 cell sizes where deposits dominate; off where a source launches few rays (the
     // work per source of the previous call of this stage, like the sectors per task) and the emptier steps cost more
     // than the merged atomics save. DRT_PHASE_WINDOW overrides.
@@ -1167,6 +1169,18 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         return DRT_OK;
     };
     HIPCHK(c, hipEventRecord(c->ev0, 0));
+    // an attempt that overflowed and is about to be undone: its device time stays in kernel_ms (ev0 is recorded again for the
+    // next attempt), and it is counted
+    double ms_undone = 0.0;
+    auto attempt_failed = [&]() -> int {
+        float ms_a = 0;
+        HIPCHK(c, hipEventRecord(c->ev1, 0));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        HIPCHK(c, hipEventElapsedTime(&ms_a, c->ev0, c->ev1));
+        ms_undone += ms_a;
+        c->cnt.retries++;
+        return DRT_OK;
+    };
     // Sub-tree tasks (StageArgs::export_level) for the `nsub` sources of `sub_list` (device): phase 1 traces their 192 nside-4
     // rays, one sector per task, and exports the blocked ones (at most 192 per source); phase 2 runs one task per child pixel
     // of an exported ray. `first`/`stride`: the phase-1 tasks this rank takes. ovf: a queue overflowed (state to be restored).
@@ -1181,7 +1195,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         if (!c->d_spawn_counter) HIPCHK(c, hipMalloc((void**)&c->d_spawn_counter, sizeof(int)));
         StageArgs keep = a;
         a.src_list = sub_list; a.nsources = nsub; a.sectors_per_task = 1; a.heavy = nullptr; a.n_heavy = 0;
-        a.spawn = c->d_spawn; a.spawn_cap = c->spawn_cap; a.spawn_counter = c->d_spawn_counter;
+            a.spawn = c->d_spawn; a.spawn_cap = c->spawn_cap; a.spawn_counter = c->d_spawn_counter;
         HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
         a.export_level = 4; a.spawn_count = 0;
         a.task_first = first; a.task_stride = stride;
@@ -1227,6 +1241,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if ((rc = subtree(c->d_src_list, (int)list.size(), c->par.id_mpi, c->par.np_mpi, max_blocks, ovf, fewer))) return rc;
             if (fewer) { max_blocks = std::max(1, std::min(max_blocks, (int)((48ll * (long long)list.size() + 3) / 4)) / 2); continue; }
             if (!ovf) break;
+            if ((rc = attempt_failed())) return rc;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
             if (max_blocks <= 1) return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
             max_blocks = (max_blocks + 1) / 2;
@@ -1300,10 +1315,11 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 HIPCHK(c, hipMemsetAsync(c->d_psel_cnt, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
             }
             HIPCHK(c, hipEventRecord(c->ev0, 0));
-            bool ovf = false, fewer = false;
+            bool ovf = false, fewer = false, ovf_sub = false;
             if (!deep.empty()) {
                 if ((rc = subtree(c->d_deep, (int)deep.size(), 0, 1, max_blocks, ovf, fewer))) return rc;
                 if (fewer) { max_blocks = std::max(1, max_blocks / 2); continue; }
+                ovf_sub = ovf;
             }
             if (!ovf && heavy.size() + light.size() > 0) {
                 a.sectors_per_task = Gtry;
@@ -1320,8 +1336,17 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 if ((rc = overflowed(ovf))) return rc;
             }
             if (!ovf) break;
-            c->overflow_met = true;
+            if ((rc = attempt_failed())) return rc;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
+            if (ovf_sub) {
+                // the sub-tree tasks of the deep sources overflowed: they run one sector (then one nside-8 pixel) per task
+                // whatever Gtry is, so only deeper queues help - fewer waves. The light tasks never ran: neither Gtry nor the
+                // remembered G_cell has anything to learn from this.
+                if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;
+                else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
+                continue;
+            }
+            c->overflow_met = true;
             if (Gtry > 1) Gtry /= 2;                  // shorter queues first,
             else if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;  // then fewer waves with deeper ones
             else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
@@ -1338,7 +1363,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->cnt.kernel_ms = ms;
+    c->cnt.kernel_ms = ms + ms_undone;
     if ((rc = check_device_error(c))) return rc;
     if ((rc = pull_counters(c))) return rc;
     if (!psrc && c->cnt.sources > 0) {
@@ -1478,7 +1503,13 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
     // every rank's next deal (build_src_list)
     if ((rc = allreduce_sum(c, c->d_src_cost, (size_t)c->N))) return rc;
     c->cost_synced = true;
-    if (c->psel_av && c->d_psel_sum) {  // reduce_psel_av_arr (io_routines.f90:3859-3881); sums and counts, a source's tasks may be spread over ranks here
+    if (c->psel_av && rt_type != DRT_RTT_PRECALC_SRC) {  // reduce_psel_av_arr (io_routines.f90:3859-3881); sums and counts, a source's tasks may be spread over ranks here
+        // every rank issues these two collectives or none does: the condition is the flag alone (drt_rt_loop allocates and
+        // zeroes the arrays on every rank, also on one that has no source of its own)
+        if (!c->d_psel_sum) {
+            if ((rc = dev_zero(c, &c->d_psel_sum, (size_t)c->N + c->nsrc))) return rc;
+            if ((rc = dev_zero(c, &c->d_psel_cnt, (size_t)c->N + c->nsrc))) return rc;
+        }
         if ((rc = allreduce_sum(c, c->d_psel_sum, (size_t)c->N + c->nsrc))) return rc;
         if ((rc = allreduce_sum(c, c->d_psel_cnt, (size_t)c->N + c->nsrc))) return rc;
     }

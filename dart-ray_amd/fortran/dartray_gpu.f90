@@ -27,7 +27,7 @@ module dartray_c
   type, bind(C) :: drt_counters
      integer(c_int64_t) :: intersections, rays, deposits, scaspe_adds, lambda_deposits, u_adds, u_reads, scaspe_slots, sources
      real(c_double) :: kernel_ms
-     integer(c_int64_t) :: launches, atomic_instructions, atomic_lanes, heavy_tasks, deep_sources
+     integer(c_int64_t) :: launches, atomic_instructions, atomic_lanes, heavy_tasks, deep_sources, retries
   end type drt_counters
 
   interface

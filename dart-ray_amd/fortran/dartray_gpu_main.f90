@@ -29,7 +29,7 @@ program dartray_gpu_main
      ! test_run of the reference (rt_routines.f90:492-493, io_routines.f90:3201-3203): everything but the RT loops
      print '(a,i0,a,i0,a,i0,a,i0)', 'dartray_gpu_main: test_run, tot_ncell ', tot_ncell, ' lnum ', lnum, ' point sources ', tot_p_src, ' directions ', tot_ndir
      print '(a,3es24.16)', 'dartray_gpu_main: dens_arr(first, ref, last wavelength) max ', maxval(dens_arr(0,:)), maxval(dens_ref), maxval(dens_arr(lnum-1,:))
-     print '(a,2es24.16)', 'dartray_gpu_main: lum_p_src_arr(first, last wavelength) ', lum_p_src_arr(0,0), lum_p_src_arr(lnum-1,0)
+     if (tot_p_src > 0) print '(a,2es24.16)', 'dartray_gpu_main: lum_p_src_arr(first, last wavelength) ', lum_p_src_arr(0,0), lum_p_src_arr(lnum-1,0)
      stop
   endif
   call gpu_grid_initialize

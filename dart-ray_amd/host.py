@@ -40,7 +40,7 @@ class Counters(C.Structure):
                 ("lambda_deposits", C.c_int64), ("u_adds", C.c_int64), ("u_reads", C.c_int64), ("scaspe_slots", C.c_int64),
                 ("sources", C.c_int64), ("kernel_ms", C.c_double), ("launches", C.c_int64),
                 ("atomic_instructions", C.c_int64), ("atomic_lanes", C.c_int64),
-                ("heavy_tasks", C.c_int64), ("deep_sources", C.c_int64)]
+                ("heavy_tasks", C.c_int64), ("deep_sources", C.c_int64), ("retries", C.c_int64)]
 
 
 EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_set_grid", "drt_set_params",
@@ -68,6 +68,16 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise DartRayError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        # ONE HIP runtime per process. The torch wheel bundles its own libamdhip64.so / libhsa-runtime64.so (SONAME
+        # libamdhip64.so.7, but NEEDED by libc10_hip.so under the file name libamdhip64.so). Mapped first, that copy also
+        # satisfies this library's NEEDED libamdhip64.so.7 and the process holds one runtime. Mapped second - a lazy
+        # `import torch` from device_tensor() / attach_process_group() after contexts exist - glibc does not match the file
+        # name against /opt/rocm's copy, maps torch's runtime beside it, and the second runtime finds no device ("No HIP GPUs
+        # are available", tools/repro_torch_late_init.py). So torch, where it is installed, is imported before the library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, i32, dp, ip = C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)
         L.drt_create.argtypes = [C.POINTER(vp), C.c_int]
@@ -230,9 +240,9 @@ class DartRayGPU:
         rt = RTT[rt] if isinstance(rt, str) else rt
         fields = {"u_fest": self.device_tensor("u_fest"), "u_final": self.device_tensor("u_final"),
                   "src_cost": self.device_tensor("src_cost"), "src_cost_done": self.mark_cost_reduced}
-        if getattr(self, "psel_on", False):
-            fields["psel"] = [self.device_tensor("psel_sum"), self.device_tensor("psel_cnt")]
         if rt != RTT["precalc_src"]:
+            if getattr(self, "psel_on", False):   # on every rank or on none: the flag decides, not whether this rank had sources
+                fields["psel"] = [self.device_tensor("psel_sum"), self.device_tensor("psel_cnt")]
             fields["lum_lost"] = self.device_tensor("lum_lost")
             fields["lum_lost_prev"] = self.device_tensor("lum_lost_prev")
             fields["scaspe"] = [self.device_tensor("scaspe", il) for il in range(self.L)]

@@ -43,11 +43,14 @@ def _steps(rt_type: int, f: Dict[str, object], npr: int):
         steps.append((f["lum_lost"], None))
     else:
         raise ValueError(f"rt_mpi: rt_type {rt_type} has no reduction (io_routines.f90:3697)")
+    # reduce_psel_av_arr (io_routines.f90:3859-3881; rt_mpi calls it after dir_src and scatt only), as sums and counts: a
+    # source's tasks may be spread over the ranks here. Whether these two sums are in the list depends on the print_psel_av
+    # flag alone, which is the same on every rank - never on whether this rank traced anything.
+    if rt_type != RTT_PRECALC_SRC:
+        for t in f.get("psel", []):
+            steps.append((t, None))
     # not in the reference: the measured wave time per cell source (DRT_A_SRC_COST), known to the rank that traced it, is
     # what every rank deals the next stage's sources by
-    # reduce_psel_av_arr (io_routines.f90:3859-3881), as sums and counts: a source's tasks may be spread over the ranks here
-    for t in f.get("psel", []):
-        steps.append((t, None))
     if f.get("src_cost") is not None:
         steps.append((f["src_cost"], f.get("src_cost_done")))
     return steps

@@ -101,12 +101,14 @@ typedef struct drt_counters {
     int64_t u_reads;       /* u_fest reads of the blocked branch (:2477) */
     int64_t scaspe_slots;  /* scaspe elements read-modify-written (sum of npix over scaspe_adds) */
     int64_t sources;       /* sources processed by the last rt_loop */
-    double kernel_ms;      /* device time of the ray-tracing kernel(s) of the last rt_loop (hipEvent) */
+    double kernel_ms;      /* device time of the ray-tracing kernel(s) of the last rt_loop (hipEvent), attempts that overflowed
+                              and were undone included (`retries`) */
     int64_t launches;      /* kernel launches behind kernel_ms */
     int64_t atomic_instructions; /* f64 atomic wave-instructions issued for scaspe / u_final by the deposit loop */
     int64_t atomic_lanes;  /* active lanes summed over those instructions (8 bytes of payload each) */
     int64_t heavy_tasks;   /* last rt_loop: tasks of cell sources cut into fewer sectors per task (measured-cost scheduling) */
     int64_t deep_sources;  /* last rt_loop: cell sources run as sub-tree tasks */
+    int64_t retries;       /* last rt_loop: attempts undone after a ray queue outgrew its arena slice and repeated with deeper queues */
 } drt_counters;
 
 /* ---- life cycle ------------------------------------------------------------------------------- */
@@ -179,9 +181,19 @@ int32_t drt_cnflag(const drt_ctx *ctx);
 int drt_calc_sed(drt_ctx *ctx, double *sed);
 int drt_get_counters(const drt_ctx *ctx, drt_counters *out);
 /* The cells THIS rank traces in drt_rt_loop / drt_rt_loop_iobs(rt_type) - the loop `i = im*np_mpi + id_mpi` of
- * rt_routines.f90:1003-1016 after its skips (parents, zero luminosity). Cell sources are shared among the np_mpi ranks
- * (contiguous blocks in cell order; DRT_PARTITION=mod: the reference's round-robin deal); point sources are listed on
- * every rank, which then runs every np_mpi-th (source, sector) task of them (rt_routines.f90:1356-1358). */
+ * rt_routines.f90:1003-1016 after its skips (parents, zero luminosity). Cell sources are shared among the np_mpi ranks in
+ * chunks of at most 64 consecutive emitting cells (DRT_PARTITION_CHUNK), dealt by EXPECTED COST, heaviest chunk to the
+ * least loaded rank (longest-processing-time-first; drt_deal_by_cost is that function). The expected cost of a source is
+ * its measured wave time in the previous launch of the same kind of stage (DRT_A_SRC_COST) scaled with its luminosity -
+ * used only once those times have been summed over the ranks (drt_rt_mpi, or drt_mark_cost_reduced after the host's own
+ * reduction) - and sqrt(luminosity) otherwise, so the deal is the same on every rank. The environment variable
+ * DRT_PARTITION selects another deal: `mod` = the reference's every-np-th cell, `block` = one contiguous block per rank,
+ * `cyclic` = the chunks dealt round the ranks. Point sources are listed on every rank, which then runs every np_mpi-th
+ * (source, sector) task of them (rt_routines.f90:1356-1358).
+ * The list returned is the one a drt_rt_loop(rt_type) called NOW would trace: it holds for the current state of the costs
+ * (it changes when drt_rt_mpi / drt_mark_cost_reduced mark them as summed, and after every launch). Side effects: the
+ * query uploads the list to the device source list and recomputes the expected costs, as drt_rt_loop itself does before
+ * a launch; nothing a following drt_rt_loop relies on. */
 int drt_get_sources(drt_ctx *ctx, int32_t rt_type, int32_t *cells, int32_t capacity, int32_t *count);
 int drt_reset_counters(drt_ctx *ctx);
 

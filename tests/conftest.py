@@ -29,18 +29,12 @@ def load_pkg():
     return mod
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _torch_sees_the_gpu_first():
-    """On a GPU box: let torch initialise its HIP state before the library creates contexts and arenas (torch's lazy
-    initialisation, reached late from a test that aliases device buffers, failed with "No HIP GPUs are available" when
-    a dozen library contexts had come and gone before it). Nothing happens without a GPU."""
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
-    yield
+# No torch.cuda.init() here any more. Round 2 initialised torch first in a session fixture because its lazy initialisation,
+# reached late from a test that aliases device buffers, failed with "No HIP GPUs are available". The cause is now known
+# (tools/repro_torch_late_init.py): the torch wheel bundles its own HIP/HSA runtime, and a process that maps
+# /opt/rocm's copy first (the library loaded before torch) ends up with two runtimes, the second of which sees no device.
+# host.lib() imports torch before it loads the library, so the product path is protected, not just the tests
+# (tests/test_abi.py::test_one_hip_runtime_in_the_process).
 
 
 @pytest.fixture(scope="session")

@@ -158,3 +158,31 @@ def test_deal_by_cost_is_a_balanced_partition_in_chunks(pkg):
     counts = np.bincount(eq, minlength=npr) // 64
     assert counts.max() - counts.min() <= 1 and counts.sum() == 33
     assert np.array_equal(host.deal_by_cost(cost, 1, chunk), np.zeros(n, dtype=np.int32))
+
+
+def test_one_hip_runtime_in_the_process(pkg):
+    """The torch wheel bundles its own libamdhip64.so / libhsa-runtime64.so; libdartray_rt.so is linked against /opt/rocm's.
+    Both carry the SONAME libamdhip64.so.7, but libc10_hip.so asks for the FILE name libamdhip64.so: when the library is
+    mapped first, torch's copy is mapped beside it and the second runtime finds no GPU ("No HIP GPUs are available" from
+    torch's lazy initialisation - round 2's open item). host.lib() therefore imports torch before it loads the library;
+    whichever of the two a caller touches first, the process must hold ONE HIP and ONE HSA runtime. Run in a child
+    process: this one has usually imported torch already."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "pkg = ge._load_pkg()\n"
+        "pkg.host.lib()\n"          # the product's loader FIRST, torch only afterwards (device_tensor() / attach_process_group())
+        "import torch\n"
+        "hip, hsa = set(), set()\n"
+        "for line in open('/proc/self/maps'):\n"
+        "    p = line.split()[-1]\n"
+        "    if 'libamdhip64' in p: hip.add(p)\n"
+        "    if 'libhsa-runtime64' in p: hsa.add(p)\n"
+        "print(len(hip), len(hsa), sorted(hip), sorted(hsa))\n"
+    ) % (ROOT,)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n_hip, n_hsa = out.stdout.split()[:2]
+    assert (n_hip, n_hsa) == ("1", "1"), out.stdout

@@ -101,17 +101,18 @@ def test_queue_overflow_is_undone_and_retried(name, golden, pkg):
         lp *= 2
     # room for 64-ray queues of 16 waves, 256 waves asked for: the library must also come down in waves by itself
     g = pkg.DartRayGPU(case, arena_bytes=_arena_for_cap(pkg, 16, lp, 512), waves=256)
-    launches = {}
+    launches, retries = {}, {}
     g.rt_prepare("start")
     for rt in ("precalc_cell", "precalc_src"):
-        g.rt_loop(rt); launches[rt] = g.counters()["launches"]
+        g.rt_loop(rt); launches[rt] = g.counters()["launches"]; retries[rt] = g.counters()["retries"]
     g.rt_mpi("precalc_src")
     assert relmax(g.u_fest, z["u_fest"]) <= RTOL
     g.rt_prepare("prep_part2")
     for rt in ("dir_cell", "dir_src"):
-        g.rt_loop(rt); launches[rt] = g.counters()["launches"]
+        g.rt_loop(rt); launches[rt] = g.counters()["launches"]; retries[rt] = g.counters()["retries"]
     g.rt_mpi("dir_src")
     assert launches["dir_cell"] > 1, launches     # at least one undo + retry with fewer sectors per task
+    assert retries["dir_cell"] >= 1 and sum(retries.values()) >= 2, retries   # and the undone attempts are counted (drt_counters.retries)
     assert relmax(g.u_final, z["u_final_dir"]) <= RTOL and relelem(g.u_final, z["u_final_dir"]) <= RTOL_ELEM
     assert relmax(g.lum_lost, z["lum_lost_dir"]) <= 1e-7
     for il in range(g.L):
@@ -492,6 +493,65 @@ def test_psel_av_matches_reference(name, golden, pkg):
     assert relmax(got, ref) <= 1e-12 and relelem(got, ref) <= 1e-10
     assert relmax(g.u_final, z["u_final"]) <= RTOL     # and the run itself is what it was
     g.close()
+
+
+def test_psel_av_with_a_rank_that_has_no_cell_sources(golden, pkg, monkeypatch):
+    """Two ranks, psel_av on, and a deal that leaves rank 1 without a single cell source (one chunk holds them all): that rank
+    returns early from drt_rt_loop, yet it must own zeroed psel sums and counts - rt_mpi reduces them on EVERY rank (a rank that
+    skipped the two collectives would hang RCCL; one that kept the previous stage's sums would add them to everybody's) - and end
+    with the same averages and fields as the rank that traced everything (reduce_psel_av_arr, io_routines.f90:3859-3881)."""
+    import os
+    import torch
+    from dartray_amd import parallel
+    monkeypatch.setenv("DRT_PARTITION", "cyclic")
+    monkeypatch.setenv("DRT_PARTITION_CHUNK", "1000000")
+    name = "blobB"
+    z, path = golden(name)
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", name + "_pselav.npz"))["psel_av"]
+    case = pkg.grids.read_case(path, name)
+    ranks = [pkg.DartRayGPU(case, np_mpi=2, id_mpi=r) for r in (0, 1)]
+    for g in ranks:
+        g.set_psel_av(True)
+        g.rt_prepare("start")
+    assert len(ranks[1].sources("precalc_cell")) == 0 and len(ranks[0].sources("precalc_cell")) > 0
+
+    def mpi(rt):
+        torch.cuda.synchronize()
+        fields = [g.mpi_fields(rt) for g in ranks]
+        if rt != "precalc_src":
+            assert all(len(f["psel"]) == 2 for f in fields)   # both ranks bring both arrays to the reduction
+        parallel.rt_mpi_local(pkg.host.RTT[rt], fields)
+        torch.cuda.synchronize()
+
+    for rt in ("precalc_cell", "precalc_src"):
+        for g in ranks:
+            g.rt_loop(rt)
+    mpi("precalc_src")
+    for g in ranks:
+        g.rt_prepare("prep_part2")
+    for rt in ("dir_cell", "dir_src"):
+        for g in ranks:
+            g.rt_loop(rt)
+    mpi("dir_src")
+    rows = [[g.get_array("psel_av")] for g in ranks]
+    while True:
+        cn = [g.scatt_prepare() for g in ranks]
+        assert cn[0] == cn[1]
+        if cn[0]:
+            break
+        assert len(ranks[1].sources("scatt")) == 0
+        for g in ranks:
+            g.rt_loop("scatt")
+        mpi("scatt")
+        for r, g in zip(rows, ranks):
+            r.append(g.get_array("psel_av"))
+    for r, g in zip(rows, ranks):
+        got = np.array(r)
+        assert got.shape == ref.shape
+        assert np.array_equal(got > 0, ref > 0)
+        assert relmax(got, ref) <= 1e-12 and relelem(got, ref) <= 1e-10
+        assert relmax(g.u_final, z["u_final"]) <= RTOL
+        g.close()
 
 
 def test_fortran_main_prints_psel_av(pkg, tmp_path):
