@@ -47,7 +47,7 @@ stage("iobs_dir", lambda: (g.rt_loop_iobs("i_obs_dir_cell"), g.rt_loop_iobs("i_o
 it = 0
 if os.environ.get("DRT_SKIP_SCATT_ATOMICS"):
     g.L_.drt_debug_flags.argtypes = [C.c_void_p, C.c_int]
-    g.L_.drt_debug_flags(g.h, 1)
+    g.L_.drt_debug_flags(g.h, int(os.environ["DRT_SKIP_SCATT_ATOMICS"]))  # 1: no atomics, 3: no deposit at all (builds with -DDRT_DEBUG_FLAGS)
 while not g.scatt_prepare():
     it += 1
     stage(f"scatt{it}", lambda: g.rt_loop("scatt")); g.rt_mpi("scatt")
