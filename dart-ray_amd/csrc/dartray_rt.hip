@@ -7,6 +7,7 @@
 // needs a gfx950 device.
 #include "../../include/dartray_rt.h"
 #include "rt_wide.hpp"
+#include "rt_log.hpp"
 
 #include <dlfcn.h>
 #include <math.h>
@@ -128,6 +129,18 @@ struct drt_ctx {
     int* d_deep = nullptr;
     size_t deep_cap = 0;
     bool overflow_met = false;
+    // deposit log (rt_wide.hpp MODE 2, rt_log.hpp)
+    bool use_log = false;
+    size_t log_bytes = 0;            // 0: default
+    char* d_log = nullptr;
+    unsigned long long *d_log_idx = nullptr, *d_log_sorted = nullptr, *d_log_start = nullptr, *d_log_bsum = nullptr;
+    unsigned *d_log_chunk_count = nullptr, *d_log_cell_count = nullptr, *d_log_cursor = nullptr;
+    int *d_log_used = nullptr, *d_log_rcounter = nullptr;
+    int log_nchunks = 0;
+    unsigned log_chunk_bytes = 1u << 20, log_chunk_idx = 1u << 14;
+    int log_batches[16] = {0};       // per rt_type: batches the stage's launches were cut into last time (0: not run yet)
+    long long log_chunks_last[16] = {0};  // per rt_type: chunks the stage filled last time, all batches together
+    double log_ms = 0;               // last rt_loop: device time of the reduce passes (inside kernel_ms)
     int* d_dbg = nullptr;
     int dbg_cap = 0, dbg_flags = 0;
     double* d_ring_tab[14] = {nullptr}, *d_phi0_tab[14] = {nullptr}, *d_phi1_tab[14] = {nullptr};
@@ -228,6 +241,10 @@ extern "C" int drt_destroy(drt_ctx* c)
     for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
     if (c->d_dir_out_sc) (void)hipFree(c->d_dir_out_sc);
     for (int k = 0; k < 14; k++) if (c->d_hgnorm[k]) (void)hipFree(c->d_hgnorm[k]);
+    {
+        void* lp[] = {c->d_log, c->d_log_idx, c->d_log_sorted, c->d_log_start, c->d_log_bsum, c->d_log_chunk_count, c->d_log_cell_count, c->d_log_cursor, c->d_log_used, c->d_log_rcounter};
+        for (void* q : lp) if (q) (void)hipFree(q);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     drt_comm_destroy(c);
@@ -538,7 +555,7 @@ static int upload_problem(drt_ctx* c)
     }
     P.arena = c->d_arena;
     P.counters = c->d_counters; P.error = c->d_error; P.task_counter = c->d_task; P.src_cost = c->d_src_cost;
-    P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap; P.dbg_flags = c->dbg_flags; P.iobs_healpix = (c->algorithm == DRT_RTA_I_OBS) ? 1 : 0;
+    P.dbg = c->d_dbg; P.dbg_cap = c->dbg_cap; P.dbg_flags = c->dbg_flags; if (const char* e = getenv("DRT_DBG_FLAGS")) P.dbg_flags |= atoi(e); P.iobs_healpix = (c->algorithm == DRT_RTA_I_OBS) ? 1 : 0;
     for (int k = 0; k < 14; k++) { P.ring_tab[k] = c->d_ring_tab[k]; P.phi0_tab[k] = c->d_phi0_tab[k]; P.phi1_tab[k] = c->d_phi1_tab[k]; }
     P.tab_max_level = c->tab_max_level;
     for (int k = 0; k < 14; k++) P.hgnorm[k] = c->d_hgnorm[k];
@@ -559,16 +576,16 @@ template <int LP> static int stage_blocks_per_cu()
 }
 
 static size_t wide_lds_bytes(const drt_ctx* c) { return (4ull * DRT_LDS_WORDS(c->L, c->LP) + (c->LP > 1 ? DRT_TAB_WORDS : 0)) * sizeof(double); }
-template <int LP, bool BIG> static int wide_blocks_per_cu_(drt_ctx* c)
+template <int LP, int MODE> static int wide_blocks_per_cu_(drt_ctx* c)
 {
     int nb = 0;
     const size_t lds = wide_lds_bytes(c);
-    if (hipFuncSetAttribute((const void*)rt_stage_wide<LP, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide<LP, BIG>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipFuncSetAttribute((const void*)rt_stage_wide<LP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) (void)hipGetLastError();
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide<LP, MODE>, 256, lds) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
-// the smaller of the two instantiations' answers: the arena is carved once for both
-template <int LP> static int wide_blocks_per_cu(drt_ctx* c) { return std::min(wide_blocks_per_cu_<LP, false>(c), wide_blocks_per_cu_<LP, true>(c)); }
+// the smallest of the instantiations' answers (0: rows by atomics, 1: with the memory-table path, 2: deposit log): the arena is carved once for all
+template <int LP> static int wide_blocks_per_cu(drt_ctx* c) { return std::min(wide_blocks_per_cu_<LP, 0>(c), std::min(wide_blocks_per_cu_<LP, 1>(c), wide_blocks_per_cu_<LP, 2>(c))); }
 
 static int ensure_arena(drt_ctx* c)
 {
@@ -1044,13 +1061,74 @@ template <int LP> static void launch_stage(drt_ctx* c, const StageArgs& a, int b
 }
 template <int LP> static void launch_wide(drt_ctx* c, const StageArgs& a, int blocks)
 {
-    // slot tables with more slots than lanes (kp >= 2) need the instantiation with the memory-table path
-    if (c->big_tables) hipLaunchKernelGGL((rt_stage_wide<LP, true>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
-    else hipLaunchKernelGGL((rt_stage_wide<LP, false>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
+    // deposit log: the rows are added by k_log_reduce afterwards; otherwise slot tables with more slots than lanes (kp >= 2)
+    // need the instantiation with the memory-table path
+    if (a.log) hipLaunchKernelGGL((rt_stage_wide<LP, 2>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
+    else if (c->big_tables) hipLaunchKernelGGL((rt_stage_wide<LP, 1>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
+    else hipLaunchKernelGGL((rt_stage_wide<LP, 0>), dim3(blocks), dim3(256), wide_lds_bytes(c), 0, c->d_prob, a);
 }
 template <int LP> static void launch_iobs(drt_ctx* c, int rt, int nsrc, int blocks)
 {
     hipLaunchKernelGGL(rt_iobs_kernel<LP>, dim3(blocks), dim3(256), 0, 0, c->d_prob, rt, c->d_src_list, nsrc);
+}
+
+// ---- deposit log (rt_wide.hpp MODE 2, rt_log.hpp) --------------------------------------------------------------------------
+static int ensure_log(drt_ctx* c)
+{
+    if (c->d_log) return DRT_OK;
+    size_t bytes = c->log_bytes ? c->log_bytes : (16ull << 30);
+    if (const char* e = getenv("DRT_LOG_GB")) bytes = (size_t)std::max(1, atoi(e)) << 30;
+    if (const char* e = getenv("DRT_LOG_MB")) bytes = (size_t)std::max(8, atoi(e)) << 20;   // tests: a log that forces batches
+    // index words per chunk: a record is 16 bytes + 8 per wavelength it has room for; a chunk whose index fills first is left early
+    c->log_chunk_idx = c->log_chunk_bytes / (16u + 8u * (unsigned)std::max(1, c->L / 4));
+    const size_t per_chunk = (size_t)c->log_chunk_bytes + 16ull * c->log_chunk_idx;  // records + index words + sorted offsets
+    c->log_nchunks = (int)std::min<size_t>(bytes / per_chunk, 1u << 30);
+    if (c->log_nchunks < 4) return fail(c, DRT_E_ARG, "deposit log of %zu bytes is too small", bytes);
+    const size_t nidx = (size_t)c->log_nchunks * c->log_chunk_idx;
+    HIPCHK(c, hipMalloc((void**)&c->d_log, (size_t)c->log_nchunks * c->log_chunk_bytes));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_idx, nidx * 8));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_sorted, nidx * 8));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_chunk_count, (size_t)c->log_nchunks * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_cell_count, (size_t)c->N * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_cursor, (size_t)c->N * 4));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_start, ((size_t)c->N + 1) * 8));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_bsum, ((size_t)c->N / DRT_SCAN_BLOCK + 2) * 8));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_used, sizeof(int)));
+    HIPCHK(c, hipMalloc((void**)&c->d_log_rcounter, sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_log_used, 0, sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_log_chunk_count, 0, (size_t)c->log_nchunks * 4));
+    HIPCHK(c, hipMemset(c->d_log_cell_count, 0, (size_t)c->N * 4));
+    return DRT_OK;
+}
+
+// The records the last launch left in the log are binned by cell and every cell's rows are added to scaspe; the log is
+// empty afterwards. `used`: chunks the launch filled (returned for the batch planning of the next call).
+static int log_reduce(drt_ctx* c, int* used_out, bool may_skip = false)
+{
+    int used = 0;
+    HIPCHK(c, hipMemcpy(&used, c->d_log_used, sizeof(int), hipMemcpyDeviceToHost));
+    used = std::min(used, c->log_nchunks);
+    if (used_out) *used_out = used;
+    const bool no_reduce = may_skip && getenv("DRT_LOG_NOREDUCE") != nullptr;  // timing aid: the records of a scattering iteration are dropped
+    if (used > 0 && no_reduce) HIPCHK(c, hipMemsetAsync(c->d_log_chunk_count, 0, (size_t)used * 4, 0));
+    if (used > 0 && !no_reduce) {
+        const int N = c->N, nb = (N + DRT_SCAN_BLOCK - 1) / DRT_SCAN_BLOCK;
+        // (the records per cell were counted by the tracing kernel as it wrote them)
+        HIPCHK(c, hipMemsetAsync(c->d_log_cursor, 0, (size_t)N * 4, 0));
+        const dim3 g((unsigned)used, (unsigned)std::max(1u, c->log_chunk_idx / 1024u));
+        hipLaunchKernelGGL(k_log_scan_sums, dim3(nb), dim3(256), 0, 0, c->d_log_cell_count, N, c->d_log_bsum);
+        hipLaunchKernelGGL(k_log_scan_top, dim3(1), dim3(64), 0, 0, c->d_log_bsum, nb);
+        hipLaunchKernelGGL(k_log_scan_fin, dim3(nb), dim3(64), 0, 0, c->d_log_cell_count, N, c->d_log_bsum, c->d_log_start, nb);
+        hipLaunchKernelGGL(k_log_scatter, g, dim3(256), 0, 0, c->d_log_idx, c->d_log_chunk_count, c->log_chunk_idx, c->d_log_start, c->d_log_cursor, c->d_log_sorted);
+        HIPCHK(c, hipMemsetAsync(c->d_log_rcounter, 0, sizeof(int), 0));
+        const int blocks = std::min(N, c->ncu * 16);
+        hipLaunchKernelGGL(k_log_reduce16<4>, dim3(blocks), dim3(64), 0, 0, c->d_prob, c->d_log, c->d_log_start, c->d_log_sorted, N, (c->L + 3) / 4, c->d_log_rcounter);
+        HIPCHK(c, hipMemsetAsync(c->d_log_chunk_count, 0, (size_t)used * 4, 0));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_log_cell_count, 0, (size_t)c->N * 4, 0));
+    HIPCHK(c, hipMemsetAsync(c->d_log_used, 0, sizeof(int), 0));
+    HIPCHK(c, hipGetLastError());
+    return DRT_OK;
 }
 
 extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
@@ -1100,6 +1178,32 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     a.export_level = 0; a.spawn_count = 0; a.spawn = nullptr; a.spawn_cap = 0; a.spawn_counter = nullptr;
     a.task_first = 0; a.task_stride = 1;
     a.heavy = nullptr; a.n_heavy = 0; a.record_cost = cell_stage ? 1 : 0;
+    // Deposit log (rt_wide.hpp MODE 2): the stages that scatter leave records, the rows are added per cell afterwards.
+    // DRT_LOG=1 switches it on (ray-major kernel only).
+    a.log = nullptr; a.log_idx = nullptr; a.log_chunk_count = nullptr; a.log_chunks_used = nullptr; a.log_cell_count = nullptr;
+    a.log_chunk_bytes = 0; a.log_chunk_idx = 0; a.log_nchunks = 0;
+    {
+        const char* e = getenv("DRT_LOG");
+        c->use_log = e && e[0] == '1' && c->ray_major;
+    }
+    const bool use_log = c->use_log && direct;
+    if (use_log) {
+        if ((rc = ensure_log(c))) return rc;
+        a.log = c->d_log; a.log_idx = c->d_log_idx; a.log_chunk_count = c->d_log_chunk_count; a.log_chunks_used = c->d_log_used; a.log_cell_count = c->d_log_cell_count;
+        a.log_chunk_bytes = c->log_chunk_bytes; a.log_chunk_idx = c->log_chunk_idx; a.log_nchunks = c->log_nchunks;
+    }
+    // batches: a stage whose records do not fit the log at once is cut into `nbatch` launches, every one followed by its
+    // reduce pass; batch b takes the tasks b, b + nbatch, ... (an even mix of heavy and light ones). Planned from the chunks
+    // the same stage filled last time; a launch that still overflows the log is undone and the stage repeated with twice as many.
+    int nbatch = 1;
+    if (use_log) {
+        const long long last = c->log_chunks_last[rt_type & 15];
+        if (last > 0) nbatch = (int)std::max(1ll, (last * 5 / 4 + c->log_nchunks - 1) / c->log_nchunks);
+        else if (c->log_batches[rt_type & 15] > 0) nbatch = c->log_batches[rt_type & 15];
+        if (const char* e = getenv("DRT_LOG_BATCHES")) nbatch = std::max(1, atoi(e));
+    }
+    long long log_chunks_total = 0;
+    bool ovf_log = false;
     a.psel_sum = nullptr; a.psel_cnt = nullptr;
     if (c->psel_av) { a.psel_sum = c->d_psel_sum; a.psel_cnt = c->d_psel_cnt; }
     // Phase window (trace_items_w): 1.5 cell sizes where deposits dominate; off where a source launches few rays (the
@@ -1164,9 +1268,37 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     auto overflowed = [&](bool& ovf) -> int {
         int e = 0;
         HIPCHK(c, hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
-        ovf = (e & ERR_CAPACITY) && !(e & ~ERR_CAPACITY);
+        ovf = (e & (ERR_CAPACITY | ERR_LOG)) && !(e & ~(ERR_CAPACITY | ERR_LOG));
+        ovf_log = ovf && (e & ERR_LOG) && !(e & ERR_CAPACITY);  // only the log was too small: more batches, same queues
         if (ovf) HIPCHK(c, hipMemset(c->d_error, 0, sizeof(int)));
         return DRT_OK;
+    };
+    // one launch of the stage kernel over the tasks a.task_first + k * a.task_stride - or, with the deposit log, nbatch
+    // launches over disjoint shares of them, each followed by its reduce pass
+    int nbatch_sub = 0;   // batches of the sub-tree launches of a cell stage (0: as many as the stage's own)
+    bool in_subtree = false;
+    auto run_batches = [&](int nblocks, bool& ovf) -> int {
+        const int B = use_log ? ((in_subtree && nbatch_sub > 0) ? nbatch_sub : nbatch) : 1;
+        const int f0 = a.task_first, s0 = a.task_stride;
+        int rcb = DRT_OK;
+        ovf = false;
+        for (int b = 0; b < B && !ovf && !rcb; b++) {
+            a.task_first = f0 + s0 * b; a.task_stride = s0 * B;
+            rcb = (hipMemset(c->d_task, 0, sizeof(int)) == hipSuccess) ? DRT_OK : fail(c, DRT_E_HIP, "hipMemset(d_task)");
+            if (rcb) break;
+            // every wave that writes records holds a chunk of the log: with a small log fewer waves run (half the chunks at most)
+            launch(use_log ? std::max(1, std::min(nblocks, c->log_nchunks / 8)) : nblocks);
+            c->cnt.launches++;
+            if ((rcb = overflowed(ovf))) break;
+            if (use_log) {
+                int used = 0;
+                if (ovf) { (void)hipMemset(c->d_log_used, 0, sizeof(int)); (void)hipMemset(c->d_log_chunk_count, 0, (size_t)c->log_nchunks * 4); (void)hipMemset(c->d_log_cell_count, 0, (size_t)c->N * 4); }
+                else if ((rcb = log_reduce(c, &used, rt_type == DRT_RTT_SCATT))) break;
+                log_chunks_total += used;
+            }
+        }
+        a.task_first = f0; a.task_stride = s0;
+        return rcb;
     };
     HIPCHK(c, hipEventRecord(c->ev0, 0));
     // an attempt that overflowed and is about to be undone: its device time stays in kernel_ms (ev0 is recorded again for the
@@ -1194,6 +1326,8 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         }
         if (!c->d_spawn_counter) HIPCHK(c, hipMalloc((void**)&c->d_spawn_counter, sizeof(int)));
         StageArgs keep = a;
+        in_subtree = true;
+        struct Leave { bool& f; ~Leave() { f = false; } } leave{in_subtree};
         a.src_list = sub_list; a.nsources = nsub; a.sectors_per_task = 1; a.heavy = nullptr; a.n_heavy = 0;
             a.spawn = c->d_spawn; a.spawn_cap = c->spawn_cap; a.spawn_counter = c->d_spawn_counter;
         HIPCHK(c, hipMemset(c->d_spawn_counter, 0, sizeof(int)));
@@ -1207,12 +1341,9 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (rc2 == DRT_E_CAPACITY && blocks1 > 1) { retry_fewer = true; return DRT_OK; }
             return rc2;
         }
-        HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-        launch(blocks1);
-        c->cnt.launches++;
+        if ((rc2 = run_batches(blocks1, ovf))) { a = keep; return rc2; }
         int nspawn = 0;
         HIPCHK(c, hipMemcpy(&nspawn, c->d_spawn_counter, sizeof(int), hipMemcpyDeviceToHost));
-        if ((rc2 = overflowed(ovf))) { a = keep; return rc2; }
         if (!ovf && nspawn > 0) {
             a.export_level = 0; a.spawn_count = std::min(nspawn, c->spawn_cap);
             a.task_first = 0; a.task_stride = 1;  // phase 2 runs what THIS rank exported
@@ -1220,10 +1351,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             int blocks2 = (int)std::max(1ll, std::min((nt + 3) / 4, (long long)max_blocks));
             while ((rc2 = carve_arena(c, blocks2 * 4, a)) == DRT_E_CAPACITY && blocks2 > 1) blocks2 = (blocks2 + 1) / 2;
             if (rc2) { a = keep; return rc2; }
-            HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-            launch(blocks2);
-            c->cnt.launches++;
-            if ((rc2 = overflowed(ovf))) { a = keep; return rc2; }
+            if ((rc2 = run_batches(blocks2, ovf))) { a = keep; return rc2; }
         }
         a = keep;
         return DRT_OK;
@@ -1243,6 +1371,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (!ovf) break;
             if ((rc = attempt_failed())) return rc;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
+            if (ovf_log) { if (nbatch >= 4096) return fail(c, DRT_E_CAPACITY, "deposit log too small"); nbatch *= 2; log_chunks_total = 0; continue; }
             if (max_blocks <= 1) return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
             max_blocks = (max_blocks + 1) / 2;
         }
@@ -1276,14 +1405,21 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             light.clear(); heavy.clear(); deep.clear();
             double total = 0;
             for (int i : list) total += c->src_pred_h[(size_t)i];
+            nbatch_sub = 0;
             if (!(heavy_div > 0) || !(total > 0)) { light = list; return; }
-            const double limit = total / (double)c->waves / heavy_div;
+            // a stage cut into nbatch launches (deposit log): every launch is 1/nbatch of the work, and it is the launch that a task must not be a large part of
+            const double limit = total / (double)c->waves / heavy_div / (double)nbatch;
             std::vector<std::pair<double, int>> hv;
             for (int i : list) {
                 const double v = c->src_pred_h[(size_t)i];
                 if (v / 48.0 > limit) deep.push_back(i);
                 else if (v * Gbase / 48.0 > limit) hv.push_back({v, i});
                 else light.push_back(i);
+            }
+            {   // the deep sources' share of the records decides how many batches their sub-tree launches need
+                double dsum = 0;
+                for (int i : deep) dsum += c->src_pred_h[(size_t)i];
+                nbatch_sub = std::max(1, std::min(nbatch, (int)ceil(2.0 * nbatch * dsum / total)));
             }
             std::stable_sort(hv.begin(), hv.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
             for (auto& h : hv) {
@@ -1330,14 +1466,12 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                     if (rc == DRT_E_CAPACITY && blocks > 1) { if ((rc = copy_state(false))) return rc; max_blocks = (blocks + 1) / 2; continue; }
                     return rc;
                 }
-                HIPCHK(c, hipMemset(c->d_task, 0, sizeof(int)));
-                launch(blocks);
-                c->cnt.launches++;
-                if ((rc = overflowed(ovf))) return rc;
+                if ((rc = run_batches(blocks, ovf))) return rc;
             }
             if (!ovf) break;
             if ((rc = attempt_failed())) return rc;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
+            if (ovf_log) { if (nbatch >= 4096) return fail(c, DRT_E_CAPACITY, "deposit log too small"); nbatch *= 2; log_chunks_total = 0; continue; }
             if (ovf_sub) {
                 // the sub-tree tasks of the deep sources overflowed: they run one sector (then one nside-8 pixel) per task
                 // whatever Gtry is, so only deeper queues help - fewer waves. The light tasks never ran: neither Gtry nor the
@@ -1355,7 +1489,8 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         c->overflow_met = false;
     }
     HIPCHK(c, hipGetLastError());
-    if (direct && c->ray_major && c->LP > 1)
+    if (use_log) { c->log_batches[rt_type & 15] = nbatch; c->log_chunks_last[rt_type & 15] = log_chunks_total; }
+    if (direct && c->ray_major && c->LP > 1 && !use_log)
         for (int il = 0; il < c->L; il++)
             if (c->npix[il] < c->nstride[il] && c->npix[il] < 64)
                 hipLaunchKernelGGL(k_fold_pad, dim3((c->N + 255) / 256), dim3(256), 0, 0, c->d_scaspe[il], c->d_u_final, c->N, c->L, il, c->npix[il], c->nstride[il]);

@@ -19,7 +19,8 @@ enum { RTT_PRECALC_CELL = 1, RTT_PRECALC_SRC = 2, RTT_DIR_CELL = 5, RTT_I_OBS_DI
 enum { RAY_HIGH = 0, RAY_LOW = 1, RAY_RECO = 2, RAY_GONE = 3, RAY_ROOT = 4 };  // ROOT: first ray of a sub-tree task
 enum { ST_CONT = 0, ST_GO_HIGH = 1, ST_GONE = 2, ST_GO_LOW = 3, ST_OUT = 4 };
 // error bits
-enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64, ERR_TABLE = 128 };
+enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE = 8, ERR_STEPS = 16, ERR_RELOCATE = 32, ERR_MERGE = 64, ERR_TABLE = 128,
+       ERR_LOG = 256 };  // the deposit log is full (recoverable like ERR_CAPACITY: the launch is undone and repeated in more batches)
 
 // counters[] slots
 enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7,

@@ -47,6 +47,16 @@ struct StageArgs {
     int record_cost;    // add every task's duration to DevProblem::src_cost[cell] (cell-source stages)
     // phase-alignment window of the ray-major kernel in cell sizes (0 = every busy ray steps every time), see trace_items_w
     double phase_win;
+    // deposit log (rt_stage_wide<LP, 2>, see rt_wide.hpp): log = log_nchunks chunks of log_chunk_bytes; log_idx = per chunk
+    // log_chunk_idx index words (cell | byte offset / 8 << 27, one per record); log_chunk_count[k] = records of chunk k;
+    // *log_chunks_used = chunks handed out so far
+    char* log;
+    unsigned long long* log_idx;
+    unsigned* log_chunk_count;
+    unsigned* log_cell_count;   // [N]: records per cell of the launch
+    int* log_chunks_used;
+    unsigned log_chunk_bytes, log_chunk_idx;
+    int log_nchunks;
 };
 
 struct ListView {

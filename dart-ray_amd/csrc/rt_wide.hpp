@@ -308,12 +308,29 @@ __device__ __forceinline__ unsigned long long flush_lambda(const DevProblem& P, 
 
 // trace_items of rt_kernels.hpp with lane = ray. Ilds: [L][64] LDS intensities of the wave, thg: [L][64]
 // arena, ll: [L] LDS lum_lost of the running task.
-template <int LP, bool BIG>
+// ---- deposit log (MODE 2) -----------------------------------------------------------------------------------------------
+// The scattered energy of a step is not spread over the scaspe rows by the tracing kernel: every ray that scatters in its
+// cell appends ONE record to a log - key {cell, HEALPix level and pixel of its direction}, the mask of the wavelengths the
+// record has room for, and C = en_sca / HG norm of those wavelengths - and k_log_reduce (dartray_rt.hip) later goes through
+// the records of each cell, computes the Henyey-Greenstein weights of all its rays and adds every row once. Why: the
+// weights are ~12 dependent f64 instructions per (ray, wavelength); inside this kernel they run at three waves per SIMD
+// between spills (2.7 s of the 4.2 s bench step, measured by leaving them out), in a kernel of their own at full occupancy
+// they take a tenth of that, and the 7.7e10 memory-side atomic requests of the rows (3.8 s of atomic-unit time) are gone.
+// Log memory: chunks of StageArgs::log_chunk_bytes taken with one atomic each; a wave fills its chunk record by record
+// and writes one index word per record (cell | byte offset / 8 << 27) into the chunk's index region, so that the reduce
+// pass can bin the records by cell without parsing them.
+struct WaveLog { int cur; unsigned used, nidx; };  // wave-uniform: current chunk (-1: none yet), bytes and index words used in it
+#define DRT_LOG_HDR 16  // bytes in front of a record's C values: key, mask
+__device__ __forceinline__ unsigned long long log_key(int cell, int nsl, int ipix) { return (unsigned long long)(unsigned)cell | ((unsigned long long)(unsigned)nsl << 27) | ((unsigned long long)(unsigned)ipix << 32); }
+
+template <int LP, int MODE>
 __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageArgs& a, const SrcInfo& S, int mode, const ListView in, int n_in,
                               const ListView outH, int& nH, const ListView outL, int& nL, const ListView stg,
                               int* __restrict__ ostat, int level, iptr_t Ilds, double* __restrict__ thg, ldouble* ll, ldouble* bst, ldouble* opq,
-                              const SlotTabs& T, const HotP& H, const LaneTab& LT, WideCounters& wc, int& err)
+                              const SlotTabs& T, const HotP& H, const LaneTab& LT, WideCounters& wc, int& err, WaveLog& WL)
 {
+    constexpr bool BIG = (MODE == 1);    // some slot table has more slots than lanes: memory-table path in flush_lambda
+    constexpr bool LOGM = (MODE == 2);   // scattered energy goes to the deposit log
     const int lane = lane_id();
     const int L = (LP == 1) ? 1 : H.L;  // one wavelength: the wavelength loops fold away (-4.5 % on the 85 801-cell grid)
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -585,12 +602,31 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                 // one 64-byte request per (cell, wavelength); the sums of a chunk's wavelengths, gathered in LDS by cell and
                 // sent as ONE instruction with the lanes (cell, wavelength), are one or two requests per cell - the step runs
                 // at the request rate of the memory-side atomic unit.
-                constexpr bool UB = (LP > 1);
+                constexpr bool UB = (LP > 1) || LOGM;
                 ldouble* const ubuf = opq + 3 * 64 * DRT_OPQ_OF(LP);                   // [OPQ][64]
                 __attribute__((address_space(3))) int* const lead_lane = (__attribute__((address_space(3))) int*)(ubuf + 64 * DRT_OPQ_OF(LP));
                 const unsigned long long Mbr = __ballot(br != 0);
+                // log mode: the lead lane of every depositing ray's cell, found once per step (the u_final sums of a cell
+                // are gathered in LDS under that lane), and the ray's record of this step
+                int mylead = lane, rec_first = -1;
+                unsigned long long leaders_step = 0ull;
+                double* rec_c = nullptr;
+                if constexpr (LOGM) {
+                    if (a.scatter || precalc) {
+                        unsigned long long rem = Mbr;
+                        while (rem) {
+                            const int src = __ffsll((long long)rem) - 1;
+                            const int cc_b = __builtin_amdgcn_readlane(cc_s, src);
+                            const unsigned long long gm = __ballot(cc_s == cc_b) & Mbr;
+                            rem &= ~gm;
+                            mylead = ((gm >> lane) & 1ull) ? src : mylead;
+                            leaders_step |= 1ull << src;
+                        }
+                    }
+                }
                 while (lam_any) {
                     unsigned long long chunk_leaders = 0ull;
+                    bool cany = false;  // log mode: this ray scatters at some wavelength of the chunk
                     if (UB && (a.scatter || precalc)) {
 #pragma unroll
                         for (int q = 0; q < OPQ; q++) ubuf[q * 64 + lane] = 0.0;
@@ -635,7 +671,16 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                             }
                             TSTAMP(td1);
                             TACC(t_dep, td0, td1);
-                            if (a.scatter || precalc) {
+                            if constexpr (LOGM) {
+                                // u_final: summed per cell in LDS under the cell's lead lane; C waits in the ray's own LDS slot
+                                // (the operand it replaces has been read) for the record written at the end of the chunk
+#ifdef DRT_DEBUG_FLAGS
+                                if (!(rt == RTT_SCATT && (P.dbg_flags & 16)))   // timing variant: no u_final sums
+#endif
+                                if (U != 0.0) (void)__hip_atomic_fetch_add(ubuf + q * 64 + mylead, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                opq[(3 * q) * 64 + lane] = C;
+                                cany = cany || (C != 0.0);
+                            } else if (a.scatter || precalc) {
                                 const unsigned long long MC = __ballot(C != 0.0);
                                 const unsigned long long M = MC | __ballot(U != 0.0);
                                 if (M) {
@@ -650,6 +695,61 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                                     __builtin_amdgcn_wave_barrier();
                                 }
+                            }
+                        } else if constexpr (LOGM) {
+                            opq[(3 * q) * 64 + lane] = 0.0;
+                        }
+                    }
+                    if constexpr (LOGM) {
+                        chunk_leaders = leaders_step;
+                        // records: a ray gets its record in the first chunk in which it scatters, with room for every wavelength
+                        // it carries from that chunk's first one on (rays in cells without dust never get one)
+#ifdef DRT_DEBUG_FLAGS
+                        const bool need = a.scatter && cany && rec_first < 0 && !(rt == RTT_SCATT && (P.dbg_flags & 4));   // timing variant: no records
+#else
+                        const bool need = a.scatter && cany && rec_first < 0;
+#endif
+                        const unsigned long long bneed = __ballot(need);
+                        if (bneed) {
+                            const int lf = lq[0];
+                            const unsigned long long rmask = amask & ~((1ull << lf) - 1ull);
+                            const unsigned sz = need ? (unsigned)(DRT_LOG_HDR + 8 * __popcll(rmask)) : 0u;
+                            unsigned incl = sz;
+                            for (int off = 1; off < 64; off <<= 1) { const unsigned t = (unsigned)__shfl_up((int)incl, off, 64); if (lane >= off) incl += t; }
+                            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                            const unsigned nrec = (unsigned)__popcll(bneed);
+                            if (WL.cur < 0 || WL.used + total > a.log_chunk_bytes || WL.nidx + nrec > a.log_chunk_idx) {
+                                // next chunk: the old one's index count is published, a new one is taken
+                                int k = 0;
+                                if (lane == 0) {
+                                    if (WL.cur >= 0) a.log_chunk_count[WL.cur] = WL.nidx;
+                                    k = atomicAdd(a.log_chunks_used, 1);
+                                }
+                                k = first_lane_i(k);
+                                if (k >= a.log_nchunks) { err |= ERR_LOG; WL.cur = -1; }
+                                else { WL.cur = k; WL.used = 0u; WL.nidx = 0u; }
+                            }
+                            if (WL.cur >= 0 && need) {
+                                const unsigned long long boff = (unsigned long long)(unsigned)WL.cur * a.log_chunk_bytes + WL.used + (incl - sz);
+                                unsigned long long* const rec = (unsigned long long*)(a.log + boff);
+                                rec[0] = log_key(cc_s, nsl, hgpix);
+                                rec[1] = rmask;
+                                rec_c = (double*)(rec + 2);
+                                rec_first = lf;
+                                a.log_idx[(unsigned long long)(unsigned)WL.cur * a.log_chunk_idx + WL.nidx + (unsigned)__popcll(bneed & lanemask_lt())] = (unsigned long long)(unsigned)cc_s | ((boff >> 3) << 27);
+                                atomicAdd(a.log_cell_count + cc_s, 1u);   // records per cell, for the reduce pass's binning (no return value: the atomic unit has room)
+                            }
+                            if (WL.cur >= 0) { WL.used += total; WL.nidx += nrec; }
+                        }
+                        if (rec_first >= 0) {
+                            const unsigned long long rmask = amask & ~((1ull << rec_first) - 1ull);
+#pragma unroll
+                            for (int q = 0; q < OPQ; q++) {
+                                const int l = lq[q];
+#ifdef DRT_DEBUG_FLAGS
+                                if (rt == RTT_SCATT && (P.dbg_flags & 8)) continue;   // timing variant: records allocated, C not stored
+#endif
+                                if (l >= 0 && ((rmask >> l) & 1ull)) rec_c[__popcll(rmask & ((1ull << l) - 1ull))] = opq[(3 * q) * 64 + lane];
                             }
                         }
                     }
@@ -761,9 +861,10 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 // luminosity arrays in the queues (next power of two >= lnum); BIG: some slot table has more slots than lanes (kp >= 2),
 // the instantiation without it has no memory-table path in its deposit loop.
 // Dynamic LDS: per wave DRT_LDS_WORDS(L, LP) doubles.
-template <int LP, bool BIG>
+template <int LP, int MODE>
 __global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
 {
+    constexpr bool LOGM = (MODE == 2);
     extern __shared__ double lds_w[];
     const DevProblem& P = *Pp;
     const int lane = lane_id();
@@ -797,9 +898,10 @@ __global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const Dev
     const int rt = a.rt_type;
     WideCounters wc = {};
     int err = 0;
+    WaveLog WL = {-1, 0u, 0u};
     TSTAMP(tk0);
     HotP H;
-    H.u_pad = a.scatter ? 1 : 0;
+    H.u_pad = (a.scatter && !LOGM) ? 1 : 0;  // log mode: no row atomics for u_final to ride in
     H.L = L; H.tau_thin = P.tau_thin; H.cs = P.cs; H.en_lim = P.en_lim;
     H.dens = P.dens; H.u_fest_r = P.u_fest; H.u_fest = P.u_fest; H.u_final = P.u_final;
     if (rt == RTT_PRECALC_SRC || rt == RTT_PRECALC_CELL) H.u_final = P.u_fest;  // the accumulator of these stages
@@ -918,7 +1020,7 @@ __global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const Dev
             }
             const ListView in = (mode == 0) ? Hc : Hn;
             const ListView oh = (mode == 0) ? Hn : Hc;
-            if (n_in > 0) trace_items_w<LP, BIG>(P, a, S, mode, in, n_in, oh, n_oh, LW, nL, ST, ostat, level, Ilds, thg, ll, bst, opq, T, H, LT, wc, err);
+            if (n_in > 0) trace_items_w<LP, MODE>(P, a, S, mode, in, n_in, oh, n_oh, LW, nL, ST, ostat, level, Ilds, thg, ll, bst, opq, T, H, LT, wc, err, WL);
             wave_fence();
             if (mode == 0) {
                 ListView t = Hc; Hc = Hn; Hn = t;
@@ -977,6 +1079,7 @@ __global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const Dev
         if (err) break;
     }
     flush_counters();
+    if constexpr (LOGM) { if (lane == 0 && WL.cur >= 0) a.log_chunk_count[WL.cur] = WL.nidx; }
     if (lane == 0) {
         atomicAdd(&P.counters[CNT_ATOM], wc.atom);
         atomicAdd(&P.counters[CNT_ATOM_LANES], wc.atom_lanes);
