@@ -1557,8 +1557,11 @@ static void* rccl_sym(const char* name)
 {
     if (!g_rccl) {
         const char* env = getenv("DRT_RCCL_LIB");
+        // a copy the process already holds comes first (a host that has imported torch has torch's librccl.so mapped, built for
+        // the HIP runtime the process runs on - see host.py on the one-runtime rule)
+        if (!env) for (const char* p : {"librccl.so.1", "librccl.so"}) { g_rccl = dlopen(p, RTLD_NOW | RTLD_NOLOAD); if (g_rccl) break; }
         const char* cand[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* p : cand) { if (!p) continue; g_rccl = dlopen(p, RTLD_NOW | RTLD_GLOBAL); if (g_rccl) break; }
+        if (!g_rccl) for (const char* p : cand) { if (!p) continue; g_rccl = dlopen(p, RTLD_NOW | RTLD_GLOBAL); if (g_rccl) break; }
     }
     return g_rccl ? dlsym(g_rccl, name) : nullptr;
 }
@@ -1597,6 +1600,40 @@ extern "C" int drt_comm_destroy(drt_ctx* c)
         c->comm = nullptr;
     }
     return DRT_OK;
+}
+
+// The library's own RCCL path end to end on ONE rank: the library is found and its entry points resolved, a one-rank
+// communicator is made from a fresh unique id (passed by value, as ncclCommInitRank wants it), a device buffer goes through
+// ncclAllReduce(double, sum) in place on the library's stream and must come back as it went in, the communicator is destroyed.
+// What a node with several GPUs adds is the transport; everything this library does with RCCL is exercised here.
+extern "C" int drt_comm_selftest(drt_ctx* c)
+{
+    if (!c) return DRT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    nccl_get_uid_t f_uid = (nccl_get_uid_t)rccl_sym("ncclGetUniqueId");
+    nccl_init_rank_t f_init = (nccl_init_rank_t)rccl_sym("ncclCommInitRank");
+    nccl_allreduce_t f_ar = (nccl_allreduce_t)rccl_sym("ncclAllReduce");
+    nccl_destroy_t f_des = (nccl_destroy_t)rccl_sym("ncclCommDestroy");
+    if (!f_uid || !f_init || !f_ar || !f_des) return fail(c, DRT_E_COMM, "RCCL library not found or incomplete (set DRT_RCCL_LIB)");
+    drt_uid u;
+    int r = f_uid(u.b);
+    if (r != 0) return fail(c, DRT_E_COMM, "ncclGetUniqueId failed (%d)", r);
+    void* comm = nullptr;
+    if ((r = f_init(&comm, 1, u, 0)) != 0) return fail(c, DRT_E_COMM, "ncclCommInitRank(1 rank) failed (%d)", r);
+    const size_t n = 4096;
+    std::vector<double> h(n), back(n);
+    for (size_t k = 0; k < n; k++) h[k] = 1.0 / (double)(k + 1);
+    double* d = nullptr;
+    int rc = DRT_OK;
+    if (hipMalloc((void**)&d, n * sizeof(double)) != hipSuccess) rc = fail(c, DRT_E_HIP, "hipMalloc");
+    if (!rc && hipMemcpy(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, DRT_E_HIP, "hipMemcpy");
+    if (!rc && (r = f_ar(d, d, n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, 0)) != 0) rc = fail(c, DRT_E_COMM, "ncclAllReduce failed (%d)", r);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(c, DRT_E_HIP, "hipDeviceSynchronize after ncclAllReduce");
+    if (!rc && hipMemcpy(back.data(), d, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, DRT_E_HIP, "hipMemcpy");
+    if (!rc) for (size_t k = 0; k < n; k++) if (back[k] != h[k]) { rc = fail(c, DRT_E_COMM, "one-rank all-reduce changed element %zu", k); break; }
+    if (d) (void)hipFree(d);
+    f_des(comm);
+    return rc;
 }
 
 static int allreduce_sum(drt_ctx* c, double* d, size_t n)

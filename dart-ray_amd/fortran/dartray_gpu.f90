@@ -184,6 +184,10 @@ module dartray_c
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx
      end function drt_comm_destroy
+     integer(c_int) function drt_comm_selftest(ctx) bind(C, name='drt_comm_selftest')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function drt_comm_selftest
   end interface
 end module dartray_c
 
@@ -333,6 +337,11 @@ contains
     character(kind=c_char), intent(in) :: id(128)
     call gpu_check(drt_comm_init(gpu_ctx, int(np_mpi, c_int32_t), int(id_mpi, c_int32_t), id), 'drt_comm_init')
   end subroutine gpu_comm_init
+
+  !> The library's RCCL path on one rank (drt_comm_selftest): stops with the library's message when RCCL cannot be used here.
+  subroutine gpu_comm_selftest()
+    call gpu_check(drt_comm_selftest(gpu_ctx), 'drt_comm_selftest')
+  end subroutine gpu_comm_selftest
 
   !> rt_prepare (dartray_hub.f90:386-469) for the cases that touch the path.
   subroutine rt_prepare()

@@ -47,7 +47,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm", "drt_set_psel_av"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_comm_selftest", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm", "drt_set_psel_av"]
 
 
 def build(force: bool = False) -> str:
@@ -107,6 +107,8 @@ def lib():
         L.drt_comm_unique_id.argtypes = [C.c_char_p]
         L.drt_comm_init.argtypes = [vp, i32, i32, C.c_char_p]
         L.drt_comm_destroy.argtypes = [vp]
+        if hasattr(L, "drt_comm_selftest"):
+            L.drt_comm_selftest.argtypes = [vp]
         if hasattr(L, "drt_get_sources"):  # absent from libraries of older revisions (A/B runs through DRT_LIB)
             L.drt_get_sources.argtypes = [vp, i32, ip, i32, ip]
             L.drt_arena_carve.argtypes = [C.c_size_t, i32, i32, ip, ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -367,6 +369,10 @@ class DartRayGPU:
         return {k: getattr(c, k) for k, _ in Counters._fields_}
 
     def reset_counters(self): self._chk(self.L_.drt_reset_counters(self.h))
+
+    def comm_selftest(self):
+        """drt_comm_selftest: the library's RCCL path on one rank (raises DartRayError when it fails)."""
+        self._chk(self.L_.drt_comm_selftest(self.h))
 
     # ---- multi-GPU
     @staticmethod

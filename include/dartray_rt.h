@@ -209,6 +209,9 @@ int drt_arena_carve(size_t arena_bytes, int32_t waves, int32_t lp, int32_t *cap,
 int drt_comm_unique_id(char id[DRT_UNIQUE_ID_BYTES]);
 int drt_comm_init(drt_ctx *ctx, int32_t nranks, int32_t rank, const char id[DRT_UNIQUE_ID_BYTES]);
 int drt_comm_destroy(drt_ctx *ctx);
+/* The RCCL path of this library end to end on one rank (find the library, one-rank communicator from a fresh id,
+ * ncclAllReduce(double, sum) in place on a device buffer, destroy): DRT_OK, or DRT_E_COMM with drt_last_error(). */
+int drt_comm_selftest(drt_ctx *ctx);
 
 #ifdef __cplusplus
 }

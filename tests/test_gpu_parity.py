@@ -377,6 +377,17 @@ def test_deposit_log_matches_golden(name, log_mb, golden, pkg, monkeypatch):
     g.close()
 
 
+def test_in_library_rccl_path_on_one_rank(golden, pkg):
+    """drt_comm_init / drt_rt_mpi reach RCCL through dlopen; with one GPU per box that path had never run. drt_comm_selftest
+    runs all of it on one rank: library found, ncclGetUniqueId, ncclCommInitRank (id by value), ncclAllReduce(double, sum) in
+    place on a device buffer on the library's stream, result unchanged, ncclCommDestroy."""
+    z, path = golden("cube65")
+    case = pkg.grids.read_case(path, "cube65")
+    g = pkg.DartRayGPU(case)
+    g.comm_selftest()
+    g.close()
+
+
 def test_rt_mpi_without_communicator_is_an_error(golden, pkg):
     """np_mpi > 1 set through drt_set_params but no communicator of that size (drt_comm_init): the fields of the rank
     are partial sums, drt_rt_mpi must refuse (DRT_E_COMM = -6) instead of passing them on; and a communicator whose
