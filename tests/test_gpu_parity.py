@@ -954,3 +954,63 @@ def test_bench_workload_properties(pkg):
             if kext[i] > 2.0 * kext[j]:
                 assert frac[i] > frac[j], (i, j)
     assert (lost / emitted < 0.01).all()
+
+
+def test_bench_grid_sample_of_sources_matches_oracle(pkg, tmp_path, monkeypatch):
+    """Parity at the size bench.py times: BASELINE configs[1] (TRUST-I tau_z = 1, 32 wavelengths, 85 801 cells), scattering
+    iteration 1, on the sources i = 0 (mod 256) - the reference's own deal of sources to rank 0 of 256 ranks
+    (rt_routines.f90:1003-1005), which both the oracle (set_parallel) and the library (np_mpi = 256, DRT_PARTITION=mod) follow.
+    The oracle starts from the state the library's direct-light stages left (as bench.py's cpu_baseline leg does); a second
+    library context is given the same state through drt_set_array. Rays, intersections and deposits must be equal and what the
+    sample adds to u_final, scaspe and lum_lost must agree to the tolerances of the golden tests."""
+    import os
+    m = 256
+    grids = pkg.grids
+    case = grids.trusti_case(tau_z=1.0, max_lvl=5, wavelengths=list(range(32)), max_sca_iterations=1)
+    assert case.tree.ncell == 85801
+    full = pkg.DartRayGPU(case, arena_bytes=64 << 30)
+    full.rt_prepare("start")
+    full.rt_loop("precalc_cell"); full.rt_loop("precalc_src"); full.rt_mpi("precalc_src")
+    full.rt_prepare("prep_part2")
+    full.rt_loop("dir_cell"); full.rt_loop("dir_src"); full.rt_mpi("dir_src")
+    state = {"u_final": full.u_final.copy(), "u_fest": full.u_fest.copy(), "lum_lost": full.lum_lost.copy(),
+             "scaspe": [full.scaspe(il).copy() for il in range(full.L)]}
+    L = full.L
+    full.close()
+
+    path = str(tmp_path / "bench_case.bin")
+    case.write(path)
+    o = op.Oracle(path, nsrc=case.p_src_pos.shape[0], ndir=case.dir_out.shape[0])
+    np.copyto(o.u_final, state["u_final"]); np.copyto(o.u_fest, state["u_fest"]); np.copyto(o.lum_lost, state["lum_lost"])
+    for il in range(L):
+        np.copyto(o.scaspe(il), state["scaspe"][il])
+    assert not o.scatt_prepare()
+    u0_o = np.array(o.u_final).copy(); lost0_o = np.array(o.lum_lost).copy()
+    o.set_parallel(m, 0, min(16, os.cpu_count() or 1))
+    o.reset_counters(); o.rt_loop("scatt")
+    co = o.counters()
+
+    monkeypatch.setenv("DRT_PARTITION", "mod")
+    g = pkg.DartRayGPU(case, np_mpi=m, id_mpi=0, arena_bytes=64 << 30)
+    g.rt_prepare("start"); g.rt_prepare("prep_part2")
+    g.set_array("u_fest", state["u_fest"]); g.set_array("u_final", state["u_final"]); g.set_array("lum_lost", state["lum_lost"])
+    for il in range(L):
+        g.set_array("scaspe", state["scaspe"][il], il)
+    assert not g.scatt_prepare()
+    u0_g = g.u_final.copy(); lost0_g = g.lum_lost.copy()
+    assert relmax(u0_g, u0_o) <= 1e-14
+    src = g.sources("scatt")
+    assert len(src) > 100 and all(int(i) % m == 0 for i in src)
+    g.reset_counters(); g.rt_loop("scatt")
+    cg = g.counters()
+    assert (cg["intersections"], cg["rays"], cg["deposits"]) == (co["intersections"], co["rays"], co["deposits"])
+    assert cg["intersections"] > 10_000_000
+    du_g, du_o = g.u_final - u0_g, np.array(o.u_final) - u0_o
+    # the increments relative to their maximum; element by element the fields themselves (an increment is the difference of two
+    # fields ~1e11 times larger in places: its last digits are rounding of the subtraction, not of the kernels)
+    assert relmax(du_g, du_o) <= RTOL and relelem(g.u_final, np.array(o.u_final)) <= RTOL_ELEM
+    assert relmax(g.lum_lost - lost0_g, np.array(o.lum_lost) - lost0_o) <= 1e-7
+    for il in range(L):
+        a, b = g.scaspe(il), np.array(o.scaspe(il))
+        assert relmax(a, b) <= RTOL and relelem(a, b) <= RTOL_ELEM, il
+    g.close(); o.close()
