@@ -1122,7 +1122,13 @@ static int log_reduce(drt_ctx* c, int* used_out, bool may_skip = false)
         hipLaunchKernelGGL(k_log_scatter, g, dim3(256), 0, 0, c->d_log_idx, c->d_log_chunk_count, c->log_chunk_idx, c->d_log_start, c->d_log_cursor, c->d_log_sorted);
         HIPCHK(c, hipMemsetAsync(c->d_log_rcounter, 0, sizeof(int), 0));
         const int blocks = std::min(N, c->ncu * 16);
-        hipLaunchKernelGGL(k_log_reduce16<4>, dim3(blocks), dim3(64), 0, 0, c->d_prob, c->d_log, c->d_log_start, c->d_log_sorted, N, (c->L + 3) / 4, c->d_log_rcounter);
+        {
+            const char* e = getenv("DRT_LOG_LG");   // wavelengths per work item of the reduce pass (developer knob)
+            const int lg = e ? atoi(e) : 4;
+            if (lg == 2) hipLaunchKernelGGL(k_log_reduce16<2>, dim3(blocks), dim3(64), 0, 0, c->d_prob, c->d_log, c->d_log_start, c->d_log_sorted, N, (c->L + 1) / 2, c->d_log_rcounter);
+            else if (lg == 8) hipLaunchKernelGGL(k_log_reduce16<8>, dim3(blocks), dim3(64), 0, 0, c->d_prob, c->d_log, c->d_log_start, c->d_log_sorted, N, (c->L + 7) / 8, c->d_log_rcounter);
+            else hipLaunchKernelGGL(k_log_reduce16<4>, dim3(blocks), dim3(64), 0, 0, c->d_prob, c->d_log, c->d_log_start, c->d_log_sorted, N, (c->L + 3) / 4, c->d_log_rcounter);
+        }
         HIPCHK(c, hipMemsetAsync(c->d_log_chunk_count, 0, (size_t)used * 4, 0));
     }
     HIPCHK(c, hipMemsetAsync(c->d_log_cell_count, 0, (size_t)c->N * 4, 0));

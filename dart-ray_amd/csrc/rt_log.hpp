@@ -8,9 +8,10 @@
 //   k_log_scatter   index words -> record offsets grouped by cell
 //   k_log_reduce16  per (cell, group of wavelengths): the ray directions are rebuilt from their pixels (the same host-built
 //                   tables, hence the same doubles as in the tracing kernel), the Henyey-Greenstein weights of every record
-//                   are formed with the arithmetic of flush_lambda to the letter (fma forms, pow_m1p5_f) and the rows of the
+//                   are formed as flush_lambda forms them (same cosine, same x = 1 + g^2 - 2 g cos in fma form; x**-1.5 by a
+//                   first-order correction of v_rsq_f64's cube instead of the Newton step, 2e-13 apart) and the rows of the
 //                   cell are added to scaspe with plain read-modify-writes: the work item owns them.
-// Sums are taken in another order than the atomics of MODE 0 would take them; nothing else differs.
+// Sums are taken in another order than the atomics of MODE 0 would take them, the weights agree to 2e-13; nothing else differs.
 #pragma once
 #include "rt_wide.hpp"
 
@@ -236,26 +237,25 @@ __global__ void __launch_bounds__(64) k_log_reduce16(const DevProblem* __restric
                                 double C[4], x[4], y[4], w[4];
 #pragma unroll
                                 for (int j = 0; j < 4; j++) { C[j] = sh_C[q][s + 4 * g + j]; x[j] = __builtin_fma(-gb[q], cs[j], ga[q]); }
+                                // x**-1.5 = y0^3 (1 + 1.5 (1 - x y0^2)) with y0 = v_rsq_f64(x), good to e ~ 1.6e-7: the cube of the raw root
+                                // corrected to first order, error 7.5 e^2 < 2e-13 (nothing decides on the weights) - six instructions and
+                                // a chain of five instead of the Newton step's seven and seven (bench step 3.74 -> 3.67 s). The tracing
+                                // kernel keeps the Newton form: there the shorter chain re-dealt the spills and lost (rt_wide.hpp).
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                                 for (int j = 0; j < 4; j++) y[j] = __builtin_amdgcn_rsq(x[j]);
-#pragma unroll
-                                for (int j = 0; j < 4; j++) x[j] = 0.5 * x[j];
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int j = 0; j < 4; j++) w[j] = x[j] * y[j];
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int j = 0; j < 4; j++) w[j] = __builtin_fma(-w[j], y[j], 1.5);
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int j = 0; j < 4; j++) y[j] = y[j] * w[j];
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                                 for (int j = 0; j < 4; j++) w[j] = y[j] * y[j];
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int j = 0; j < 4; j++) w[j] = w[j] * y[j];
+                                for (int j = 0; j < 4; j++) { x[j] = __builtin_fma(-x[j], w[j], 1.0); w[j] = w[j] * y[j]; }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 4; j++) x[j] = __builtin_fma(1.5, x[j], 1.0);
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 4; j++) w[j] = w[j] * x[j];
                                 __builtin_amdgcn_sched_barrier(0);
                                 acc[q][b] = __builtin_fma(C[3], w[3], __builtin_fma(C[2], w[2], __builtin_fma(C[1], w[1], __builtin_fma(C[0], w[0], acc[q][b]))));
                             }
