@@ -83,6 +83,7 @@ struct drt_ctx {
     bool big_tables = false;  // some wavelength's slot table has more than 63 slots (set_npix_arr)
     int G_cell = 0;  // sectors per task that last fitted the queue arena for cell sources (0: not tried yet)
     int G_want[16] = {0};  // per rt_type: sectors per task suggested by the work per source of the last call of that stage
+    bool cheap_sources[16] = {false};  // per rt_type: the last call of that stage saw < 4000 intersections per source (no phase window)
     std::vector<double*> d_bak_scaspe;  // snapshot of the accumulators of a stage, restored when a launch is repeated
     double *d_bak_u = nullptr, *d_bak_lost = nullptr;
     unsigned long long* d_bak_cnt = nullptr;  // lane = ray kernel (rt_wide.hpp) instead of lane = (ray, wavelength)
@@ -1219,7 +1220,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     // (with u_final batched per chunk, bench step: 0.5 -> 5.18 s, 0.75 -> 4.68, 1 -> 4.43, 1.25 -> 4.35, 1.5 -> 4.35, 2 -> 4.56, 2.5 -> 4.80, 3 -> 4.90)
     // (one wavelength, bench-sized grid, after this round's register diet: 0 -> 534 ms, 0.75 -> 585, 1 -> 536, 1.25 -> 511, 1.5 -> 503, 2 -> 513, 3 -> 535;
     //  config 1, cheap sources: 0 -> 4.9 ms, 1.5 -> 5.2)
-    a.phase_win = (c->G_want[rt_type & 15] != 4) ? 1.5 : 0.0;
+    a.phase_win = c->cheap_sources[rt_type & 15] ? 0.0 : 1.5;
     if (const char* e = getenv("DRT_PHASE_WINDOW")) a.phase_win = atof(e);
     auto launch = [&](int nblocks) {
         if (c->ray_major) {
@@ -1385,11 +1386,11 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // Cell sources: G sectors per task. More sectors fill the lanes better (and merge more rays per atomic) but
         // lengthen the queues; how long they get depends on the grid. The value that fitted is kept for the next call.
         // Sectors per task. 16 fill a wave's 64 lanes with first-level rays and merge most rays per atomic: best when a
-        // source launches many rays (TRUST-I tau = 1: ~8e4 intersections per source). When a source is cheap (tau = 0.01:
-        // ~9e2) a task is a handful of steps, mostly waiting for memory, and four times as many smaller tasks keep more
-        // waves busy (12.8 -> 8.6 ms). The choice follows the intersections per source of the previous call of the same
-        // stage (a run repeats its scattering stage); first call: 8.
+        // source launches many rays (TRUST-I tau = 1: ~8e4 intersections per source) - and, since round 3, also when a source
+        // is cheap (tau = 0.01: ~9e2; see where G_want is set). The choice follows the intersections per source of the
+        // previous call of the same stage (a run repeats its scattering stage); first call: 8.
         int Gtry = c->G_want[rt_type & 15] > 0 ? c->G_want[rt_type & 15] : 8;
+        if (const char* e = getenv("DRT_SECTORS_WANT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = v; }   // developer knob: overrides the choice by work per source
         if (c->G_cell > 0) Gtry = std::min(Gtry, c->G_cell);
         Gtry = std::min(Gtry, G);
         if (const char* e = getenv("DRT_SECTORS_PER_TASK")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = std::min(Gtry, v); }
@@ -1509,7 +1510,13 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if ((rc = pull_counters(c))) return rc;
     if (!psrc && c->cnt.sources > 0) {
         const double ips = (double)(c->cnt.intersections - inter_before) / (double)c->cnt.sources;
-        c->G_want[rt_type & 15] = ips < 4000.0 ? 4 : ips < 20000.0 ? 8 : 16;
+        // Cheap sources (TRUST-I tau = 0.01: ~9e2 intersections per source) are a handful of steps per task, each a chain of
+        // memory round trips (cell, neighbour, operands): what counts is the number of rays in flight per step, and their short
+        // queues never overflow - 16 sectors (round 3, config 1: 4 sectors 5.33 ms, 8: 4.15, 16: 3.72; round 2 had measured the
+        // opposite with the agent-scope fences and the tree walk of that time). In between, 8 keeps the queues of the first,
+        // unmeasured launches short (forcing 16 there: MAGTAR scattering 13.6 against 10.0 s, N-body direct light 27.5 against 20.2 s).
+        c->cheap_sources[rt_type & 15] = ips < 4000.0;
+        c->G_want[rt_type & 15] = ips < 4000.0 ? 16 : ips < 20000.0 ? 8 : 16;
     }
     return DRT_OK;
 }
