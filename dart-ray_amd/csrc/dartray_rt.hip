@@ -1060,6 +1060,25 @@ template <int LP> static void launch_stage(drt_ctx* c, const StageArgs& a, int b
 {
     hipLaunchKernelGGL(rt_stage_kernel<LP>, dim3(blocks), dim3(256), 0, 0, c->d_prob, a);
 }
+// the two-waves-per-SIMD instantiation of the one-wavelength kernel (cheap sources); at most what stays resident is launched
+static void launch_wide_lp1w2(drt_ctx* c, const StageArgs& a, int blocks)
+{
+    const size_t lds = wide_lds_bytes(c);
+    static int per_cu[3] = {0, 0, 0};
+    const int m = a.log ? 2 : (c->big_tables ? 1 : 0);
+    if (!per_cu[m]) {
+        int nb = 0;
+        hipError_t e = (m == 2) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide_lp1w2<2>, 256, lds)
+                     : (m == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide_lp1w2<1>, 256, lds)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rt_stage_wide_lp1w2<0>, 256, lds);
+        per_cu[m] = (e == hipSuccess && nb > 0) ? nb : 1;
+        if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] rt_stage_wide_lp1w2: %d blocks per CU (occupancy query: %s)\n", per_cu[m], hipGetErrorString(e));
+    }
+    blocks = std::max(1, std::min(blocks, per_cu[m] * c->ncu));
+    if (m == 2) hipLaunchKernelGGL((rt_stage_wide_lp1w2<2>), dim3(blocks), dim3(256), lds, 0, c->d_prob, a);
+    else if (m == 1) hipLaunchKernelGGL((rt_stage_wide_lp1w2<1>), dim3(blocks), dim3(256), lds, 0, c->d_prob, a);
+    else hipLaunchKernelGGL((rt_stage_wide_lp1w2<0>), dim3(blocks), dim3(256), lds, 0, c->d_prob, a);
+}
 template <int LP> static void launch_wide(drt_ctx* c, const StageArgs& a, int blocks)
 {
     // deposit log: the rows are added by k_log_reduce afterwards; otherwise slot tables with more slots than lanes (kp >= 2)
@@ -1225,7 +1244,10 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     auto launch = [&](int nblocks) {
         if (c->ray_major) {
             switch (c->LP) {
-            case 1: launch_wide<1>(c, a, nblocks); break;
+            case 1:
+                if (c->cheap_sources[rt_type & 15] && !psrc && !getenv("DRT_LP1_THREE_WAVES")) launch_wide_lp1w2(c, a, nblocks);
+                else launch_wide<1>(c, a, nblocks);
+                break;
             case 2: launch_wide<2>(c, a, nblocks); break;
             case 4: launch_wide<4>(c, a, nblocks); break;
             case 8: launch_wide<8>(c, a, nblocks); break;
@@ -1399,12 +1421,12 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // 85 801 cells: a first-level cell costs 1 s of wave time in a 0.7 s launch, and with 8 ranks the launch is 0.09 s).
         // From the expected cost of every source (src_pred_h: the wave cycles it took in the previous launch of this kind of
         // stage, DRT_A_SRC_COST, scaled with its luminosity; sqrt(luminosity) for a first launch), with
-        // limit = ideal launch time / DRT_HEAVY_DIV (default 16, 0 = off):
+        // limit = ideal launch time / DRT_HEAVY_DIV (default 8, 0 = off):
         //  * heavy sources - a task of Gtry sectors would exceed the limit - get fewer sectors per task, down to one; their
         //    tasks are listed explicitly (StageArgs::heavy) and go first, heaviest source first;
         //  * deep sources - even one sector (1/48 of the cost on average; the sectors in the plane of a slab cost several
         //    times that) would exceed it - are run as sub-tree tasks like the point sources, before the others.
-        double heavy_div = 16.0;
+        double heavy_div = 8.0;   // 16 until round 3: no difference on config 2 (4.25 s either way) and the one-wavelength step (504 ms), 2.06 against 2.38 ms on config 1
         if (const char* e = getenv("DRT_HEAVY_DIV")) heavy_div = atof(e);
         std::vector<int> light, deep;
         std::vector<int2> heavy;
@@ -1416,10 +1438,16 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (!(heavy_div > 0) || !(total > 0)) { light = list; return; }
             // a stage cut into nbatch launches (deposit log): every launch is 1/nbatch of the work, and it is the launch that a task must not be a large part of
             const double limit = total / (double)c->waves / heavy_div / (double)nbatch;
+            // The sub-tree scheme costs two more launches (and their host round trips): it pays only where the launch is long.
+            // Config 1 (a 2 ms step, ideal launch time ~1 ms of wave time per wave): 96 deep sources -> 3.37 ms per step, none
+            // (their sectors cut one per task instead) -> 2.38 ms; with the limit at 1/8 of the ideal launch time 2.06 ms.
+            double deep_min = 1.2e7;   // shader-clock cycles of wave time per wave (~5 ms) below which no source is run as sub-tree tasks
+            if (const char* e = getenv("DRT_DEEP_MIN")) deep_min = atof(e);
+            const bool no_deep = getenv("DRT_NO_DEEP") != nullptr || total / (double)c->waves / (double)nbatch < deep_min;
             std::vector<std::pair<double, int>> hv;
             for (int i : list) {
                 const double v = c->src_pred_h[(size_t)i];
-                if (v / 48.0 > limit) deep.push_back(i);
+                if (v / 48.0 > limit && !no_deep) deep.push_back(i);
                 else if (v * Gbase / 48.0 > limit) hv.push_back({v, i});
                 else light.push_back(i);
             }
@@ -1429,6 +1457,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 nbatch_sub = std::max(1, std::min(nbatch, (int)ceil(2.0 * nbatch * dsum / total)));
             }
             std::stable_sort(hv.begin(), hv.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d)\n", rt_type, total, total / c->waves, limit, list.size(), deep.size(), hv.size(), light.size(), Gbase);
             for (auto& h : hv) {
                 int Gi = Gbase;
                 while (Gi > 1 && h.first * Gi / 48.0 > limit) Gi >>= 1;

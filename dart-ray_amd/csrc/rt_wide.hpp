@@ -69,7 +69,10 @@ typedef ldouble* iptr_t;
 #define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ_OF(LP) + 3 + 64 * DRT_OPQ_OF(LP) + 32 + 1)
 // waves per SIMD of an instantiation; four for one wavelength (128 registers, 5 KB of LDS per wave) was tried after the register
 // diet of round 2: 585 against 503 ms on the bench grid, 6.1 against 4.9 ms on config 1 - the loop still spills at 128
-#define DRT_WAVES_OF(LP) DRT_WIDE_WAVES
+#ifndef DRT_WAVES_LP1
+#define DRT_WAVES_LP1 DRT_WIDE_WAVES
+#endif
+#define DRT_WAVES_OF(LP) ((LP) == 1 ? DRT_WAVES_LP1 : DRT_WIDE_WAVES)
 struct HotP {
     int L;
     int u_pad;   // scatter stages: u_final sums ride in the padding slot of the scaspe rows (folded by the host after the launch)
@@ -864,7 +867,7 @@ __device__ __forceinline__ void trace_items_w(const DevProblem& P, const StageAr
 // the instantiation without it has no memory-table path in its deposit loop.
 // Dynamic LDS: per wave DRT_LDS_WORDS(L, LP) doubles.
 template <int LP, int MODE>
-__global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
+__device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict__ Pp, const StageArgs& a)
 {
     constexpr bool LOGM = (MODE == 2);
     extern __shared__ double lds_w[];
@@ -1098,4 +1101,19 @@ __global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const Dev
 #endif
         if (err) atomicOr(P.error, err);
     }
+}
+
+template <int LP, int MODE>
+__global__ void __launch_bounds__(256, DRT_WAVES_OF(LP)) rt_stage_wide(const DevProblem* __restrict__ Pp, StageArgs a)
+{
+    rt_stage_wide_body<LP, MODE>(Pp, a);
+}
+// One wavelength, cheap sources (TRUST-I tau = 0.01: ~9e2 intersections per source): a step is a chain of memory round trips and
+// few lanes are busy; with two waves per SIMD (256 registers) the kernel does not spill and a step is shorter - config 1:
+// 3.69 -> 3.04 ms per step. Where sources are expensive the third wave wins (85 801 cells: 510 ms against 625). The host picks
+// by the work per source of the stage's previous call (drt_ctx::cheap_sources).
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) rt_stage_wide_lp1w2(const DevProblem* __restrict__ Pp, StageArgs a)
+{
+    rt_stage_wide_body<1, MODE>(Pp, a);
 }
