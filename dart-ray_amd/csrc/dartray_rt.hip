@@ -109,6 +109,7 @@ struct drt_ctx {
     // cost_kind = that launch's rt_type (-1: nothing measured yet)
     std::vector<double> src_pred_h, cost_lum_h;
     int cost_kind = -1;
+    bool pred_measured = false;  // src_pred_h of the launch being prepared rests on measured wave times (else on the prior alone)
     int algorithm = 0;  // DRT_RTA_MAIN / DRT_RTA_I_OBS (drt_set_algorithm)
     bool psel_av = false;  // print_psel_av (drt_set_psel_av)
     double *d_psel_sum = nullptr, *d_psel_cnt = nullptr;  // [N + nsrc] each
@@ -995,6 +996,7 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool 
         // summed over the ranks (drt_rt_mpi, or the host's own reduction followed by drt_mark_cost_reduced); until then a
         // rank knows the costs of its own sources only and the deal uses the prior, a function of lumcell, alone.
         const bool use_meas = same_kind && (np == 1 || c->cost_synced);
+        c->pred_measured = use_meas && sum_meas > 0;
         for (size_t k = 0; k < list.size(); k++) {
             const size_t i = (size_t)list[k];
             if (use_meas && meas[i] > 0 && c->cost_lum_h[i] > 0) c->src_pred_h[i] = meas[i] * (lum[k] / c->cost_lum_h[i]);
@@ -1437,7 +1439,12 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             nbatch_sub = 0;
             if (!(heavy_div > 0) || !(total > 0)) { light = list; return; }
             // a stage cut into nbatch launches (deposit log): every launch is 1/nbatch of the work, and it is the launch that a task must not be a large part of
-            const double limit = total / (double)c->waves / heavy_div / (double)nbatch;
+            // Nothing measured yet (the first launch of a kind of stage: only the prior, sqrt(luminosity), whose RATIOS are good -
+            // cost / sqrt(lum) is 0.50-0.62 from the smallest to the largest cells of the bench grid - but which knows nothing of
+            // how long the queues of a task get): cut four times finer. On the bench grid the first scattering iteration then runs
+            // through at 8 sectors (4.25 s) instead of overflowing its queues, being undone and repeated at 4 (5.81 s).
+            const double hd = heavy_div * (c->pred_measured ? 1.0 : 4.0);
+            const double limit = total / (double)c->waves / hd / (double)nbatch;
             // The sub-tree scheme costs two more launches (and their host round trips): it pays only where the launch is long.
             // Config 1 (a 2 ms step, ideal launch time ~1 ms of wave time per wave): 96 deep sources -> 3.37 ms per step, none
             // (their sectors cut one per task instead) -> 2.38 ms; with the limit at 1/8 of the ideal launch time 2.06 ms.
