@@ -82,6 +82,11 @@ struct drt_ctx {
     bool ray_major = false;
     bool big_tables = false;  // some wavelength's slot table has more than 63 slots (set_npix_arr)
     int G_cell = 0;  // sectors per task that last fitted the queue arena for cell sources (0: not tried yet)
+    // per rt_type: sectors per task of the stage's last successful cell launch and the share of the queue capacity its longest
+    // queue took (CNT_QMAX / cap): more sectors are tried only where that leaves room (queues grow with the sectors of a task)
+    int G_last[16] = {0};
+    double q_fill[16] = {0.0};
+    double f_last[16] = {0.0};   // ... and the task limit of that launch as a fraction of a wave's share of the stage (1 / hd in plan())
     int G_want[16] = {0};  // per rt_type: sectors per task suggested by the work per source of the last call of that stage
     bool cheap_sources[16] = {false};  // per rt_type: the last call of that stage saw < 4000 intersections per source (no phase window)
     std::vector<double*> d_bak_scaspe;  // snapshot of the accumulators of a stage, restored when a launch is repeated
@@ -142,6 +147,7 @@ struct drt_ctx {
     unsigned log_chunk_bytes = 1u << 20, log_chunk_idx = 1u << 14;
     int log_batches[16] = {0};       // per rt_type: batches the stage's launches were cut into last time (0: not run yet)
     long long log_chunks_last[16] = {0};  // per rt_type: chunks the stage filled last time, all batches together
+    int log_peak_last[16] = {0};     // per rt_type: chunks the fullest of those batches filled
     double log_ms = 0;               // last rt_loop: device time of the reduce passes (inside kernel_ms)
     int* d_dbg = nullptr;
     int dbg_cap = 0, dbg_flags = 0;
@@ -1225,13 +1231,19 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     // the same stage filled last time; a launch that still overflows the log is undone and the stage repeated with twice as many.
     int nbatch = 1;
     if (use_log) {
-        const long long last = c->log_chunks_last[rt_type & 15];
-        if (last > 0) nbatch = (int)std::max(1ll, (last * 5 / 4 + c->log_nchunks - 1) / c->log_nchunks);
-        else if (c->log_batches[rt_type & 15] > 0) nbatch = c->log_batches[rt_type & 15];
+        // from the fullest batch of the stage's last call: the batches are not equally full (the heaviest tasks come first in the
+        // task list), and a batch that overflows costs an undone attempt and twice the batches
+        const int peak = c->log_peak_last[rt_type & 15], nb_last = c->log_batches[rt_type & 15];
+        if (peak > 0 && nb_last > 0) nbatch = (int)std::max(1.0, ceil((double)nb_last * (double)peak / (0.65 * (double)c->log_nchunks)));   // two thirds full: the fill of a batch varies by 10-20 % from call to call
+        else if (nb_last > 0) nbatch = nb_last;
         if (const char* e = getenv("DRT_LOG_BATCHES")) nbatch = std::max(1, atoi(e));
     }
     long long log_chunks_total = 0;
+    int log_peak = 0;
     bool ovf_log = false;
+    int g_used = 0;   // sectors per task of the cell launch that went through
+    double f_used_stage = 0.0;   // and its task limit as a fraction of a wave's share
+    HIPCHK(c, hipMemsetAsync(c->d_counters + CNT_QMAX, 0, sizeof(unsigned long long), 0));
     a.psel_sum = nullptr; a.psel_cnt = nullptr;
     if (c->psel_av) { a.psel_sum = c->d_psel_sum; a.psel_cnt = c->d_psel_cnt; }
     // Phase window (trace_items_w): 1.5 cell sizes where deposits dominate; off where a source launches few rays (the
@@ -1326,6 +1338,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 if (ovf) { (void)hipMemset(c->d_log_used, 0, sizeof(int)); (void)hipMemset(c->d_log_chunk_count, 0, (size_t)c->log_nchunks * 4); (void)hipMemset(c->d_log_cell_count, 0, (size_t)c->N * 4); }
                 else if ((rcb = log_reduce(c, &used, rt_type == DRT_RTT_SCATT))) break;
                 log_chunks_total += used;
+                if (!in_subtree) log_peak = std::max(log_peak, used);
             }
         }
         a.task_first = f0; a.task_stride = s0;
@@ -1402,7 +1415,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (!ovf) break;
             if ((rc = attempt_failed())) return rc;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
-            if (ovf_log) { if (nbatch >= 4096) return fail(c, DRT_E_CAPACITY, "deposit log too small"); nbatch *= 2; log_chunks_total = 0; continue; }
+            if (ovf_log) { if (nbatch >= 4096) return fail(c, DRT_E_CAPACITY, "deposit log too small"); nbatch *= 2; log_chunks_total = 0; log_peak = 0; continue; }
             if (max_blocks <= 1) return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
             max_blocks = (max_blocks + 1) / 2;
         }
@@ -1416,6 +1429,12 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         int Gtry = c->G_want[rt_type & 15] > 0 ? c->G_want[rt_type & 15] : 8;
         if (const char* e = getenv("DRT_SECTORS_WANT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = v; }   // developer knob: overrides the choice by work per source
         if (c->G_cell > 0) Gtry = std::min(Gtry, c->G_cell);
+        // more sectors per task than the stage's last launch took: only if its queues left the room (bench grid, 32 wavelengths:
+        // the launch at 8 sectors fills 60-70 % of the queues of a 200 GiB arena; trying 16 meant an overflow, an undone attempt
+        // of 3.4 s and a repeat at 8 - in the second call of every stage)
+        if (c->G_last[rt_type & 15] > 0 && !getenv("DRT_SECTORS_WANT"))
+            while (Gtry > c->G_last[rt_type & 15] && c->q_fill[rt_type & 15] * (double)Gtry / (double)c->G_last[rt_type & 15] > 0.85) Gtry /= 2;
+        double f_used = 0.0;
         Gtry = std::min(Gtry, G);
         if (const char* e = getenv("DRT_SECTORS_PER_TASK")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = std::min(Gtry, v); }
         int max_blocks = c->waves / 4;
@@ -1443,14 +1462,24 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             // cost / sqrt(lum) is 0.50-0.62 from the smallest to the largest cells of the bench grid - but which knows nothing of
             // how long the queues of a task get): cut four times finer. On the bench grid the first scattering iteration then runs
             // through at 8 sectors (4.25 s) instead of overflowing its queues, being undone and repeated at 4 (5.81 s).
-            const double hd = heavy_div * (c->pred_measured ? 1.0 : 4.0);
+            double hd = heavy_div * (c->pred_measured ? 1.0 : 4.0);
+            // ... and no coarser than the queues allow: the longest queue of a launch grows with its largest task. The stage's last
+            // launch had its limit at f_last of a wave's share and filled q_fill of the queue capacity (CNT_QMAX): this one may
+            // go up to f_last * 0.8 / q_fill. (Bench grid: the first launch, cut at 1/32, fills 52 %; the second, measured, would
+            // be cut at 1/8, overflow, be undone and repeated - 3.4 s lost in every run; at 1/20 it goes through.)
+            if (c->f_last[rt_type & 15] > 0 && c->q_fill[rt_type & 15] > 0) {
+                const double f_max = c->f_last[rt_type & 15] * 0.8 / c->q_fill[rt_type & 15] * (double)c->G_last[rt_type & 15] / (double)Gbase;
+                if (1.0 / hd > f_max) hd = 1.0 / f_max;
+            }
+            f_used = 1.0 / hd;
             const double limit = total / (double)c->waves / hd / (double)nbatch;
             // The sub-tree scheme costs two more launches (and their host round trips): it pays only where the launch is long.
             // Config 1 (a 2 ms step, ideal launch time ~1 ms of wave time per wave): 96 deep sources -> 3.37 ms per step, none
             // (their sectors cut one per task instead) -> 2.38 ms; with the limit at 1/8 of the ideal launch time 2.06 ms.
             double deep_min = 1.2e7;   // shader-clock cycles of wave time per wave (~5 ms) below which no source is run as sub-tree tasks
             if (const char* e = getenv("DRT_DEEP_MIN")) deep_min = atof(e);
-            const bool no_deep = getenv("DRT_NO_DEEP") != nullptr || total / (double)c->waves / (double)nbatch < deep_min;
+            // (only where the costs are measured ones: the prior has no unit)
+            const bool no_deep = getenv("DRT_NO_DEEP") != nullptr || (c->pred_measured && total / (double)c->waves / (double)nbatch < deep_min);
             std::vector<std::pair<double, int>> hv;
             for (int i : list) {
                 const double v = c->src_pred_h[(size_t)i];
@@ -1514,7 +1543,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (!ovf) break;
             if ((rc = attempt_failed())) return rc;
             if ((rc = copy_state(false))) return rc;  // undo the partial launch in any case
-            if (ovf_log) { if (nbatch >= 4096) return fail(c, DRT_E_CAPACITY, "deposit log too small"); nbatch *= 2; log_chunks_total = 0; continue; }
+            if (ovf_log) { if (nbatch >= 4096) return fail(c, DRT_E_CAPACITY, "deposit log too small"); nbatch *= 2; log_chunks_total = 0; log_peak = 0; continue; }
             if (ovf_sub) {
                 // the sub-tree tasks of the deep sources overflowed: they run one sector (then one nside-8 pixel) per task
                 // whatever Gtry is, so only deeper queues help - fewer waves. The light tasks never ran: neither Gtry nor the
@@ -1529,10 +1558,11 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
         if (c->overflow_met) c->G_cell = c->G_cell > 0 ? std::min(c->G_cell, Gtry) : Gtry;  // an overflow was met: more sectors than this do not fit this arena
+        g_used = Gtry; f_used_stage = f_used;
         c->overflow_met = false;
     }
     HIPCHK(c, hipGetLastError());
-    if (use_log) { c->log_batches[rt_type & 15] = nbatch; c->log_chunks_last[rt_type & 15] = log_chunks_total; }
+    if (use_log) { c->log_batches[rt_type & 15] = nbatch; c->log_chunks_last[rt_type & 15] = log_chunks_total; c->log_peak_last[rt_type & 15] = log_peak; }
     if (direct && c->ray_major && c->LP > 1 && !use_log)
         for (int il = 0; il < c->L; il++)
             if (c->npix[il] < c->nstride[il] && c->npix[il] < 64)
@@ -1544,6 +1574,14 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     c->cnt.kernel_ms = ms + ms_undone;
     if ((rc = check_device_error(c))) return rc;
     if ((rc = pull_counters(c))) return rc;
+    if (!psrc && g_used > 0 && c->cap > 0) {
+        unsigned long long qmax = 0;
+        HIPCHK(c, hipMemcpy(&qmax, c->d_counters + CNT_QMAX, sizeof qmax, hipMemcpyDeviceToHost));
+        c->G_last[rt_type & 15] = g_used;
+        c->q_fill[rt_type & 15] = (double)qmax / (double)c->cap;
+        c->f_last[rt_type & 15] = f_used_stage;
+        if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] rt %d: %d sectors per task, longest queue %llu of %d rays\n", rt_type, g_used, qmax, c->cap);
+    }
     if (!psrc && c->cnt.sources > 0) {
         const double ips = (double)(c->cnt.intersections - inter_before) / (double)c->cnt.sources;
         // Cheap sources (TRUST-I tau = 0.01: ~9e2 intersections per source) are a handful of steps per task, each a chain of

@@ -904,6 +904,7 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
     WideCounters wc = {};
     int err = 0;
     WaveLog WL = {-1, 0u, 0u};
+    int qhi = 0;   // the longest high / low queue this wave held (wave-uniform)
     TSTAMP(tk0);
     HotP H;
     H.u_pad = (a.scatter && !LOGM) ? 1 : 0;  // log mode: no row atomics for u_final to ride in
@@ -1049,6 +1050,7 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
                 }
             }
             nH = n_oh;
+            qhi = max(qhi, max(nH, nL));
             // define_next_level (rt_routines.f90:2745-2770)
             if (nH > 0) level *= 2;
             else if (nL > 0) level /= 2;
@@ -1086,6 +1088,7 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
     flush_counters();
     if constexpr (LOGM) { if (lane == 0 && WL.cur >= 0) a.log_chunk_count[WL.cur] = WL.nidx; }
     if (lane == 0) {
+        atomicMax(&P.counters[CNT_QMAX], (unsigned long long)qhi);
         atomicAdd(&P.counters[CNT_ATOM], wc.atom);
         atomicAdd(&P.counters[CNT_ATOM_LANES], wc.atom_lanes);
 #ifdef DRT_PROFILE
