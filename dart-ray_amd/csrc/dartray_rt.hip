@@ -81,7 +81,9 @@ struct drt_ctx {
     int L = 0, LP = 1;
     bool ray_major = false;
     bool big_tables = false;  // some wavelength's slot table has more than 63 slots (set_npix_arr)
-    int G_cell = 0;  // sectors per task that last fitted the queue arena for cell sources (0: not tried yet)
+    int G_cell[16] = {0};  // per rt_type: sectors per task that last fitted the queue arena after an overflow (0: none met). Per stage
+                           // kind since round 3: the direct light of the N-body grid overflows at 8 sectors, its scattering
+                           // iterations fill a tenth of their queues at 4 and were held there by the one global value
     // per rt_type: sectors per task of the stage's last successful cell launch and the share of the queue capacity its longest
     // queue took (CNT_QMAX / cap): more sectors are tried only where that leaves room (queues grow with the sectors of a task)
     int G_last[16] = {0};
@@ -267,7 +269,7 @@ extern "C" int drt_configure(drt_ctx* c, size_t arena_bytes, int waves)
     if (!c) return DRT_E_ARG;
     if (arena_bytes) c->arena_bytes = arena_bytes;
     if (waves > 0) c->waves = waves;
-    c->G_cell = 0;
+    for (int k = 0; k < 16; k++) c->G_cell[k] = 0;
     if (c->d_arena) { (void)hipFree(c->d_arena); c->d_arena = nullptr; }
     return DRT_OK;
 }
@@ -1428,7 +1430,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // previous call of the same stage (a run repeats its scattering stage); first call: 8.
         int Gtry = c->G_want[rt_type & 15] > 0 ? c->G_want[rt_type & 15] : 8;
         if (const char* e = getenv("DRT_SECTORS_WANT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = v; }   // developer knob: overrides the choice by work per source
-        if (c->G_cell > 0) Gtry = std::min(Gtry, c->G_cell);
+        if (c->G_cell[rt_type & 15] > 0) Gtry = std::min(Gtry, c->G_cell[rt_type & 15]);
         // more sectors per task than the stage's last launch took: only if its queues left the room (bench grid, 32 wavelengths:
         // the launch at 8 sectors fills 60-70 % of the queues of a 200 GiB arena; trying 16 meant an overflow, an undone attempt
         // of 3.4 s and a repeat at 8 - in the second call of every stage)
@@ -1557,7 +1559,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             else if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;  // then fewer waves with deeper ones
             else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
-        if (c->overflow_met) c->G_cell = c->G_cell > 0 ? std::min(c->G_cell, Gtry) : Gtry;  // an overflow was met: more sectors than this do not fit this arena
+        if (c->overflow_met) c->G_cell[rt_type & 15] = c->G_cell[rt_type & 15] > 0 ? std::min(c->G_cell[rt_type & 15], Gtry) : Gtry;  // an overflow was met: more sectors than this do not fit this arena
         g_used = Gtry; f_used_stage = f_used;
         c->overflow_met = false;
     }
