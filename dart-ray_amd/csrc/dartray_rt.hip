@@ -1475,10 +1475,11 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             }
             f_used = 1.0 / hd;
             const double limit = total / (double)c->waves / hd / (double)nbatch;
-            // The sub-tree scheme costs two more launches (and their host round trips): it pays only where the launch is long.
+            // The sub-tree scheme costs two more launches (and their host round trips): it does not pay where the launch is short.
             // Config 1 (a 2 ms step, ideal launch time ~1 ms of wave time per wave): 96 deep sources -> 3.37 ms per step, none
             // (their sectors cut one per task instead) -> 2.38 ms; with the limit at 1/8 of the ideal launch time 2.06 ms.
-            double deep_min = 1.2e7;   // shader-clock cycles of wave time per wave (~5 ms) below which no source is run as sub-tree tasks
+            double deep_min = 4.0e6;   // shader-clock cycles of wave time per wave (~1.7 ms) below which no source is run as sub-tree tasks
+                                       // (1.2e7 lost the third scattering iteration of an 8-rank run: 36.7 against 15.9 ms per rank)
             if (const char* e = getenv("DRT_DEEP_MIN")) deep_min = atof(e);
             // (only where the costs are measured ones: the prior has no unit)
             const bool no_deep = getenv("DRT_NO_DEEP") != nullptr || (c->pred_measured && total / (double)c->waves / (double)nbatch < deep_min);
