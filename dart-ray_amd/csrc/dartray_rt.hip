@@ -693,6 +693,7 @@ static const char* trace_error_text(int e)
     if (e & ERR_STEPS) return "step limit reached";
     if (e & ERR_MERGE) return "inconsistent sibling table while merging low rays";
     if (e & ERR_TABLE) return "ray finer than the HEALPix direction tables (set DRT_TAB_NSIDE to a larger power of two)";
+    if (e & ERR_LOG) return "the deposit log is full (raise DRT_LOG_GB)";
     return "unknown device error";
 }
 
@@ -1049,7 +1050,7 @@ static int check_device_error(drt_ctx* c)
     HIPCHK(c, hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
     if (e) {
         (void)hipMemset(c->d_error, 0, sizeof(int));
-        return fail(c, (e & ERR_CAPACITY) ? DRT_E_CAPACITY : DRT_E_TRACE, "device: %s (flags 0x%x)", trace_error_text(e), e);
+        return fail(c, (e & (ERR_CAPACITY | ERR_LOG)) ? DRT_E_CAPACITY : DRT_E_TRACE, "device: %s (flags 0x%x)", trace_error_text(e), e);
     }
     return DRT_OK;
 }
