@@ -2,7 +2,7 @@
 # Developer tool (GPU box): instruction and wave counters of the deposit-log kernels on the bench step, one rocprofv3 pass per group.
 set -u
 cd "${GRAFT_REPO_ROOT:-$PWD}"
-export TMPDIR=/tmp DRT_LOG=1 DRT_LOG_GB=100 DRT_LOG_RED16=${1:-4}
+export TMPDIR=/tmp DRT_LOG=1 DRT_LOG_GB=100 DRT_LOG_LG=${1:-4}
 n=0
 for c in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   n=$((n+1))
