@@ -947,6 +947,80 @@ extern "C" int drt_deal_by_cost(const double* cost, int64_t n, int32_t np, int32
     return DRT_OK;
 }
 
+// ---- task planning of a cell-source launch (pure; drt_plan_tasks exposes it for the CPU tests) -----------------------------
+// A task is one wave's serial work: no task may be a large part of its launch. From the expected cost of every source (measured
+// wave time scaled with the luminosity, or the prior sqrt(luminosity)), with limit = (sum of the costs / waves) / hd / nbatch:
+//  * deep sources  - one sector (1/48 of the source) would exceed the limit - are run as sub-tree tasks, before the others;
+//  * heavy sources - a task of G sectors would exceed it - get fewer sectors per task (a power-of-two fraction of G, down to one),
+//    their tasks listed explicitly, heaviest source first;
+//  * light sources take G sectors per task.
+// hd: base 8 (DRT_HEAVY_DIV); x 4 where nothing is measured yet (the prior's ratios are good, but it knows nothing of queue
+// lengths); and never coarser than the queues allow: the stage's last launch had its limit at f_last of a wave's share with G_last
+// sectors and filled q_fill of the queue capacity, so this one may go up to f_last * 0.8 / q_fill * G_last / G.
+// No source is deep where the costs are measured and a wave's share of the launch is below deep_min cycles (the sub-tree scheme
+// is two more launches).
+struct PlanIn {
+    const int* list; size_t n; const double* cost;   // cost[list[k]]
+    int waves, G, nbatch;
+    double heavy_div, deep_min;
+    bool measured, no_deep;
+    double f_last, q_fill; int G_last;
+};
+struct PlanOut { std::vector<int> light, deep; std::vector<int2> heavy; double f_used = 0, limit = 0, total = 0; int nbatch_sub = 0; size_t n_heavy_src = 0; };
+static void plan_tasks(const PlanIn& in, PlanOut& o)
+{
+    o.light.clear(); o.heavy.clear(); o.deep.clear(); o.f_used = 0; o.limit = 0; o.nbatch_sub = 0; o.n_heavy_src = 0;
+    double total = 0;
+    for (size_t k = 0; k < in.n; k++) total += in.cost[(size_t)in.list[k]];
+    o.total = total;
+    if (!(in.heavy_div > 0) || !(total > 0)) { o.light.assign(in.list, in.list + in.n); return; }
+    double hd = in.heavy_div * (in.measured ? 1.0 : 4.0);
+    if (in.f_last > 0 && in.q_fill > 0 && in.G_last > 0) {
+        const double f_max = in.f_last * 0.8 / in.q_fill * (double)in.G_last / (double)in.G;
+        if (1.0 / hd > f_max) hd = 1.0 / f_max;
+    }
+    o.f_used = 1.0 / hd;
+    const double limit = total / (double)in.waves / hd / (double)std::max(1, in.nbatch);
+    o.limit = limit;
+    const bool no_deep = in.no_deep || (in.measured && total / (double)in.waves / (double)std::max(1, in.nbatch) < in.deep_min);
+    std::vector<std::pair<double, int>> hv;
+    double dsum = 0;
+    for (size_t k = 0; k < in.n; k++) {
+        const int i = in.list[k];
+        const double v = in.cost[(size_t)i];
+        if (v / 48.0 > limit && !no_deep) { o.deep.push_back(i); dsum += v; }
+        else if (v * in.G / 48.0 > limit) hv.push_back({v, i});
+        else o.light.push_back(i);
+    }
+    // the deep sources' share of the records decides how many batches their sub-tree launches need (deposit log)
+    o.nbatch_sub = std::max(1, std::min(std::max(1, in.nbatch), (int)ceil(2.0 * std::max(1, in.nbatch) * dsum / total)));
+    std::stable_sort(hv.begin(), hv.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+    o.n_heavy_src = hv.size();
+    for (auto& h : hv) {
+        int Gi = in.G;
+        while (Gi > 1 && h.first * Gi / 48.0 > limit) Gi >>= 1;
+        for (int s0 = 0; s0 < 48; s0 += Gi) o.heavy.push_back(make_int2(h.second, s0 | (Gi << 8)));
+    }
+}
+
+// cls[k] of source k: 0 light, -1 deep, else the sectors per task of a heavy source. Returns the number of explicit heavy tasks.
+extern "C" int drt_plan_tasks(const double* cost, int64_t n, int32_t waves, int32_t G, int32_t nbatch, double heavy_div, double deep_min,
+                              int32_t measured, double f_last, double q_fill, int32_t G_last, int32_t* cls, double* limit_out)
+{
+    if (!cost || !cls || n < 0 || waves < 1 || (G != 1 && G != 2 && G != 4 && G != 8 && G != 16)) return DRT_E_ARG;
+    std::vector<int> list((size_t)n);
+    for (int64_t k = 0; k < n; k++) list[(size_t)k] = (int)k;
+    PlanIn in{list.data(), (size_t)n, cost, waves, G, std::max(1, (int)nbatch), heavy_div, deep_min, measured != 0, false, f_last, q_fill, G_last};
+    PlanOut o;
+    plan_tasks(in, o);
+    for (int64_t k = 0; k < n; k++) cls[k] = -2;
+    for (int i : o.light) cls[i] = 0;
+    for (int i : o.deep) cls[i] = -1;
+    for (const int2& h : o.heavy) cls[h.x] = h.y >> 8;
+    if (limit_out) *limit_out = o.limit;
+    return (int)o.heavy.size();
+}
+
 // ---- rt_loop ---------------------------------------------------------------------------------------------
 // The sources of one rt_loop call on this rank. Cell sources are shared among the ranks in CHUNKS of consecutive
 // emitting cells (DRT_PARTITION_CHUNK cells per chunk, default 64), dealt by expected cost (deal_by_cost; DRT_PARTITION=cyclic
@@ -1455,54 +1529,22 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         std::vector<int> light, deep;
         std::vector<int2> heavy;
         auto plan = [&](int Gbase) {
-            light.clear(); heavy.clear(); deep.clear();
-            double total = 0;
-            for (int i : list) total += c->src_pred_h[(size_t)i];
-            nbatch_sub = 0;
-            if (!(heavy_div > 0) || !(total > 0)) { light = list; return; }
-            // a stage cut into nbatch launches (deposit log): every launch is 1/nbatch of the work, and it is the launch that a task must not be a large part of
-            // Nothing measured yet (the first launch of a kind of stage: only the prior, sqrt(luminosity), whose RATIOS are good -
-            // cost / sqrt(lum) is 0.50-0.62 from the smallest to the largest cells of the bench grid - but which knows nothing of
-            // how long the queues of a task get): cut four times finer. On the bench grid the first scattering iteration then runs
-            // through at 8 sectors (4.25 s) instead of overflowing its queues, being undone and repeated at 4 (5.81 s).
-            double hd = heavy_div * (c->pred_measured ? 1.0 : 4.0);
-            // ... and no coarser than the queues allow: the longest queue of a launch grows with its largest task. The stage's last
-            // launch had its limit at f_last of a wave's share and filled q_fill of the queue capacity (CNT_QMAX): this one may
-            // go up to f_last * 0.8 / q_fill. (Bench grid: the first launch, cut at 1/32, fills 52 %; the second, measured, would
-            // be cut at 1/8, overflow, be undone and repeated - 3.4 s lost in every run; at 1/20 it goes through.)
-            if (c->f_last[rt_type & 15] > 0 && c->q_fill[rt_type & 15] > 0) {
-                const double f_max = c->f_last[rt_type & 15] * 0.8 / c->q_fill[rt_type & 15] * (double)c->G_last[rt_type & 15] / (double)Gbase;
-                if (1.0 / hd > f_max) hd = 1.0 / f_max;
-            }
-            f_used = 1.0 / hd;
-            const double limit = total / (double)c->waves / hd / (double)nbatch;
-            // The sub-tree scheme costs two more launches (and their host round trips): it does not pay where the launch is short.
-            // Config 1 (a 2 ms step, ideal launch time ~1 ms of wave time per wave): 96 deep sources -> 3.37 ms per step, none
-            // (their sectors cut one per task instead) -> 2.38 ms; with the limit at 1/8 of the ideal launch time 2.06 ms.
-            double deep_min = 4.0e6;   // shader-clock cycles of wave time per wave (~1.7 ms) below which no source is run as sub-tree tasks
-                                       // (1.2e7 lost the third scattering iteration of an 8-rank run: 36.7 against 15.9 ms per rank)
+            double deep_min = 4.0e6;   // shader-clock cycles of wave time per wave (~1.7 ms) below which no source is run as sub-tree tasks:
+                                       // config 1 (a 2 ms step): 96 deep sources -> 3.37 ms per step, none -> 2.38, with the limit at 1/8
+                                       // 2.06; a 5 ms threshold lost the third scattering iteration of an 8-rank run (36.7 against 15.9 ms)
             if (const char* e = getenv("DRT_DEEP_MIN")) deep_min = atof(e);
-            // (only where the costs are measured ones: the prior has no unit)
-            const bool no_deep = getenv("DRT_NO_DEEP") != nullptr || (c->pred_measured && total / (double)c->waves / (double)nbatch < deep_min);
-            std::vector<std::pair<double, int>> hv;
-            for (int i : list) {
-                const double v = c->src_pred_h[(size_t)i];
-                if (v / 48.0 > limit && !no_deep) deep.push_back(i);
-                else if (v * Gbase / 48.0 > limit) hv.push_back({v, i});
-                else light.push_back(i);
-            }
-            {   // the deep sources' share of the records decides how many batches their sub-tree launches need
-                double dsum = 0;
-                for (int i : deep) dsum += c->src_pred_h[(size_t)i];
-                nbatch_sub = std::max(1, std::min(nbatch, (int)ceil(2.0 * nbatch * dsum / total)));
-            }
-            std::stable_sort(hv.begin(), hv.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
-            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d)\n", rt_type, total, total / c->waves, limit, list.size(), deep.size(), hv.size(), light.size(), Gbase);
-            for (auto& h : hv) {
-                int Gi = Gbase;
-                while (Gi > 1 && h.first * Gi / 48.0 > limit) Gi >>= 1;
-                for (int s0 = 0; s0 < 48; s0 += Gi) heavy.push_back(make_int2(h.second, s0 | (Gi << 8)));
-            }
+            // Unmeasured launches are cut four times finer: on the bench grid the first scattering iteration runs through at 8 sectors
+            // (4.25 s) instead of overflowing its queues, being undone and repeated at 4 (5.81 s). The queue rule: the first launch,
+            // cut at 1/32, fills 52 % of the queues; the second, measured, would be cut at 1/8, overflow and be repeated - at 1/20 it
+            // goes through.
+            PlanIn in{list.data(), list.size(), c->src_pred_h.data(), c->waves, Gbase, nbatch, heavy_div, deep_min, c->pred_measured,
+                      getenv("DRT_NO_DEEP") != nullptr, c->f_last[rt_type & 15], c->q_fill[rt_type & 15], c->G_last[rt_type & 15]};
+            PlanOut o;
+            plan_tasks(in, o);
+            light.swap(o.light); heavy.swap(o.heavy); deep.swap(o.deep);
+            nbatch_sub = o.nbatch_sub;
+            f_used = o.f_used;
+            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d)\n", rt_type, o.total, o.total / c->waves, o.limit, list.size(), deep.size(), o.n_heavy_src, light.size(), Gbase);
         };
         for (;;) {
             plan(Gtry);

@@ -47,7 +47,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_comm_selftest", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm", "drt_set_psel_av"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_comm_selftest", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm", "drt_set_psel_av", "drt_plan_tasks"]
 
 
 def build(force: bool = False) -> str:
@@ -120,6 +120,8 @@ def lib():
             L.drt_set_psel_av.argtypes = [vp, i32]
         if hasattr(L, "drt_deal_by_cost"):
             L.drt_deal_by_cost.argtypes = [dp, C.c_int64, i32, i32, ip]
+        if hasattr(L, "drt_plan_tasks"):
+            L.drt_plan_tasks.argtypes = [dp, C.c_int64, i32, i32, i32, C.c_double, C.c_double, i32, C.c_double, C.c_double, i32, ip, dp]
         _lib = L
     return _lib
 
@@ -134,6 +136,19 @@ def arena_carve(arena_bytes: int, waves: int, lp: int):
     off = (C.c_uint64 * 10)()
     rc = lib().drt_arena_carve(arena_bytes, waves, lp, C.byref(cap), C.byref(hcap), C.byref(stride), off)
     return None if rc != 0 else (cap.value, hcap.value, stride.value, list(off))
+
+
+def plan_tasks(cost, waves: int, G: int, nbatch: int = 1, heavy_div: float = 8.0, deep_min: float = 4.0e6, measured: bool = True,
+               f_last: float = 0.0, q_fill: float = 0.0, G_last: int = 0):
+    """drt_plan_tasks: (cls, number of explicit heavy tasks, limit). cls[k] = 0 light, -1 deep, else sectors per task. Needs no GPU."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    cls = np.empty(cost.size, dtype=np.int32)
+    lim = C.c_double()
+    rc = lib().drt_plan_tasks(_dp(cost), cost.size, waves, G, nbatch, heavy_div, deep_min, 1 if measured else 0, f_last, q_fill, G_last,
+                              cls.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(lim))
+    if rc < 0:
+        raise ValueError(f"drt_plan_tasks: {rc}")
+    return cls, rc, lim.value
 
 
 def deal_by_cost(cost, np_mpi: int, chunk: int = 64) -> np.ndarray:

@@ -196,6 +196,13 @@ int drt_get_counters(const drt_ctx *ctx, drt_counters *out);
  * a launch; nothing a following drt_rt_loop relies on. */
 int drt_get_sources(drt_ctx *ctx, int32_t rt_type, int32_t *cells, int32_t capacity, int32_t *count);
 int drt_reset_counters(drt_ctx *ctx);
+/* Introspection (no GPU needed): how a cell-source launch of `n` sources with expected costs `cost` is cut into tasks for `waves`
+ * persistent wavefronts at `G` sectors per task (see plan_tasks in dartray_rt.hip): cls[k] = 0 light (G sectors per task), -1 deep
+ * (sub-tree tasks), else the sectors per task of a heavy source; returns the number of explicit heavy tasks, *limit = the largest
+ * cost a task may have. measured: the costs are measured wave times (else the prior); f_last / q_fill / G_last: task limit,
+ * queue fill and sectors of the stage's last launch (0: none). */
+int drt_plan_tasks(const double *cost, int64_t n, int32_t waves, int32_t G, int32_t nbatch, double heavy_div, double deep_min,
+                   int32_t measured, double f_last, double q_fill, int32_t G_last, int32_t *cls, double *limit);
 
 /* Introspection (no GPU needed): how an arena of `arena_bytes` is split among `waves` wavefronts carrying `lp`
  * (a power of two >= lnum) luminosities per ray: queue depth `cap`, hash size `hcap`, bytes per wave `stride`, and the

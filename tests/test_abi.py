@@ -186,3 +186,49 @@ def test_one_hip_runtime_in_the_process(pkg):
     assert out.returncode == 0, out.stderr[-2000:]
     n_hip, n_hsa = out.stdout.split()[:2]
     assert (n_hip, n_hsa) == ("1", "1"), out.stdout
+
+
+def test_plan_tasks_rules(pkg):
+    """drt_plan_tasks (plan_tasks in dartray_rt.hip, pure): how a cell-source launch is cut into tasks. Every source gets exactly
+    one class; a light source's task (G sectors) and a heavy source's tasks (Gi sectors, a power-of-two fraction of G) stay under
+    the limit unless Gi is already 1; the explicit heavy tasks cover each heavy source's 48 sectors once; deep = one sector alone
+    exceeds the limit; a launch planned from the prior is cut four times finer; the limit is never coarser than the queues of
+    the stage's last launch allow; and no source is deep in a short, measured launch."""
+    rng = np.random.default_rng(5)
+    n, waves, G = 5000, 3072, 16
+    cost = np.exp(rng.normal(0.0, 1.6, n)) * 1e7            # wave cycles, spread over three decades
+    cost[:5] *= 3e3                                          # a few sources far beyond the rest
+    cls, ntask, limit = pkg.host.plan_tasks(cost, waves, G, heavy_div=8.0, deep_min=0.0, measured=True)
+    per_wave = cost.sum() / waves
+    assert limit == pytest.approx(per_wave / 8.0, rel=1e-12)
+    assert set(np.unique(cls)) <= {-1, 0, 1, 2, 4, 8, 16} and (cls != -2).all()
+    light, deep, heavy = cls == 0, cls == -1, cls > 0
+    assert light.any() and deep.any() and heavy.any()
+    assert (cost[light] * G / 48.0 <= limit).all()
+    assert (cost[deep] / 48.0 > limit).all() and (cost[~deep] / 48.0 <= limit).all()
+    gi = cls[heavy]
+    assert ((cost[heavy] * gi / 48.0 <= limit) | (gi == 1)).all()          # cut until it fits, or down to one sector
+    assert (cost[heavy] * np.minimum(2 * gi, G) / 48.0 > limit)[gi < G].all()  # and no finer than needed
+    assert ntask == int((48 // gi).sum())
+    # the prior: four times finer
+    _, _, lim_prior = pkg.host.plan_tasks(cost, waves, G, heavy_div=8.0, deep_min=0.0, measured=False)
+    assert lim_prior == pytest.approx(limit / 4.0, rel=1e-12)
+    # the queue rule: last launch cut at 1/32 of a wave's share with 8 sectors filled 52 % of the queues -> at most 1/32 * 0.8 / 0.52 at 8
+    # sectors, half of that at 16
+    _, _, lim_q8 = pkg.host.plan_tasks(cost, waves, 8, heavy_div=8.0, deep_min=0.0, measured=True, f_last=1 / 32, q_fill=0.52, G_last=8)
+    assert lim_q8 == pytest.approx(per_wave / 32 * 0.8 / 0.52, rel=1e-12)
+    _, _, lim_q16 = pkg.host.plan_tasks(cost, waves, 16, heavy_div=8.0, deep_min=0.0, measured=True, f_last=1 / 32, q_fill=0.52, G_last=8)
+    assert lim_q16 == pytest.approx(lim_q8 / 2, rel=1e-12)
+    _, _, lim_room = pkg.host.plan_tasks(cost, waves, 8, heavy_div=8.0, deep_min=0.0, measured=True, f_last=1 / 32, q_fill=0.05, G_last=8)
+    assert lim_room == pytest.approx(limit, rel=1e-12)                       # plenty of room: the rule does not bind
+    # a short measured launch has no deep sources (their sectors are cut one per task instead); an unmeasured one may
+    cls_s, _, _ = pkg.host.plan_tasks(cost, waves, G, heavy_div=8.0, deep_min=10 * per_wave, measured=True)
+    assert not (cls_s == -1).any() and (cls_s[deep] == 1).all()
+    cls_u, _, _ = pkg.host.plan_tasks(cost, waves, G, heavy_div=8.0, deep_min=10 * per_wave, measured=False)
+    assert (cls_u == -1).any()
+    # batches (deposit log): every launch is 1/nbatch of the work
+    _, _, lim_b = pkg.host.plan_tasks(cost, waves, G, nbatch=6, heavy_div=8.0, deep_min=0.0, measured=True)
+    assert lim_b == pytest.approx(limit / 6.0, rel=1e-12)
+    # heavy_div = 0 switches the cutting off
+    cls0, n0, _ = pkg.host.plan_tasks(cost, waves, G, heavy_div=0.0)
+    assert (cls0 == 0).all() and n0 == 0
