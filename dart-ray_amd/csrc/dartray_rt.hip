@@ -1295,7 +1295,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     a.log_chunk_bytes = 0; a.log_chunk_idx = 0; a.log_nchunks = 0;
     {
         const char* e = getenv("DRT_LOG");
-        c->use_log = e && e[0] == '1' && c->ray_major;
+        c->use_log = e && e[0] == '1' && c->ray_major && c->N < (1 << 27);   // a record's key has 27 bits for the cell
     }
     const bool use_log = c->use_log && direct;
     if (use_log) {
