@@ -115,6 +115,8 @@ struct drt_ctx {
     // being prepared; cost_lum_h[i] = its luminosity (sum over the wavelengths) in the launch d_src_cost was measured in,
     // cost_kind = that launch's rt_type (-1: nothing measured yet)
     std::vector<double> src_pred_h, cost_lum_h;
+    std::vector<double> src_q_h;   // [N]: the longest ray queue a 48-sector task of the source would hold (measured on its tasks of the last launch
+                                   // of this kind of stage that ran it as whole sectors; 0 = not known)
     int cost_kind = -1;
     bool pred_measured = false;  // src_pred_h of the launch being prepared rests on measured wave times (else on the prior alone)
     int algorithm = 0;  // DRT_RTA_MAIN / DRT_RTA_I_OBS (drt_set_algorithm)
@@ -666,18 +668,33 @@ extern "C" int drt_arena_carve(size_t arena_bytes, int32_t waves, int32_t lp, in
     }
 }
 
+// test aid: DRT_TEST_MAX_CAP shortens the queues (>= 16 rays) so that small cases exercise the overflow paths; the
+// slices keep their stride, only less of each is used (>= 16 rays, >= 4 for one-sector tasks)
+static void test_max_cap(int sectors_per_task, int32_t& cap, int32_t& hcap)
+{
+    if (const char* e = getenv("DRT_TEST_MAX_CAP")) {
+        const int lim = std::max(sectors_per_task > 1 ? 16 : 4, atoi(e));  // a task starts with sectors_per_task rays in its queue
+        if (cap > lim) { cap = lim; hcap = 64; while (hcap < 2 * cap) hcap <<= 1; }
+    }
+}
+
+// rays per queue when `waves` wavefronts share the arena (0: too small for that many)
+static int queue_cap(const drt_ctx* c, int waves, int sectors_per_task)
+{
+    int32_t cap = 0, hcap = 0;
+    uint64_t stride = 0;
+    if (drt_arena_carve(c->arena_bytes, waves, c->LP, &cap, &hcap, &stride, nullptr) != DRT_OK) return 0;
+    test_max_cap(sectors_per_task, cap, hcap);
+    return cap;
+}
+
 static int carve_arena(drt_ctx* c, int waves, StageArgs& a)
 {
     int32_t cap = 0, hcap = 0;
     uint64_t stride = 0;
     if (drt_arena_carve(c->arena_bytes, waves, c->LP, &cap, &hcap, &stride, nullptr) != DRT_OK)
         return fail(c, DRT_E_CAPACITY, "arena of %zu bytes too small for %d waves (fewer than %d rays per queue)", c->arena_bytes, waves, DRT_MIN_CAP);
-    // test aid: DRT_TEST_MAX_CAP shortens the queues (>= 16 rays) so that small cases exercise the overflow paths; the
-    // slices keep their stride, only less of each is used (>= 16 rays, >= 4 for one-sector tasks)
-    if (const char* e = getenv("DRT_TEST_MAX_CAP")) {
-        const int lim = std::max(a.sectors_per_task > 1 ? 16 : 4, atoi(e));  // a task starts with sectors_per_task rays in its queue
-        if (cap > lim) { cap = lim; hcap = 64; while (hcap < 2 * cap) hcap <<= 1; }
-    }
+    test_max_cap(a.sectors_per_task, cap, hcap);
     a.cap = cap; a.hcap = hcap; a.wave_stride = stride;
     c->cap = a.cap; c->hcap = a.hcap; c->wave_stride = a.wave_stride;
     return DRT_OK;
@@ -762,7 +779,8 @@ static int prepare_start(drt_ctx* c)
     if ((rc = dev_zero(c, &c->d_u_final, (size_t)N * L))) return rc;
     if ((rc = dev_zero(c, &c->d_lum_lost, (size_t)L))) return rc;
     if ((rc = dev_zero(c, &c->d_lum_lost_prev, (size_t)L))) return rc;
-    if ((rc = dev_zero(c, &c->d_src_cost, (size_t)N))) return rc;
+    if ((rc = dev_zero(c, &c->d_src_cost, 2 * (size_t)N))) return rc;   // costs, then queue lengths (DevProblem::src_cost)
+    c->src_q_h.assign((size_t)N, 0.0);
     free_fields(c);
     c->iterations = 0; c->cnflag = 0; c->bm_par_cur = c->par.bm_par; c->part2 = false;
     c->prepared = true;
@@ -957,6 +975,12 @@ extern "C" int drt_deal_by_cost(const double* cost, int64_t n, int32_t np, int32
 // hd: base 8 (DRT_HEAVY_DIV); x 4 where nothing is measured yet (the prior's ratios are good, but it knows nothing of queue
 // lengths); and never coarser than the queues allow: the stage's last launch had its limit at f_last of a wave's share with G_last
 // sectors and filled q_fill of the queue capacity, so this one may go up to f_last * 0.8 / q_fill * G_last / G.
+// Queue lengths, where the sources' own are known (q48[i]: the longest queue a task of all 48 sectors of source i would hold, from
+// its tasks in the stage's last launch; queues grow with the sectors of a task, whatever its cost): a source takes the sectors per
+// task that keep its queue below 0.8 of the capacity `cap` - a heavy source by that count too - and is deep where one sector
+// does not. This replaces the rule on f_last, which knows one queue of the whole launch (TRUST-I tau = 1, 21 801 cells, 32 wavelengths,
+// 16 GiB arena: the second scattering call, now measured, held the limit that rule allowed, overflowed at 8 and at 4 sectors and ran
+// at 2).
 // No source is deep where the costs are measured and a wave's share of the launch is below deep_min cycles (the sub-tree scheme
 // is two more launches).
 struct PlanIn {
@@ -965,17 +989,20 @@ struct PlanIn {
     double heavy_div, deep_min;
     bool measured, no_deep;
     double f_last, q_fill; int G_last;
+    const double* q48 = nullptr; double cap = 0;   // q48[list[k]], 0 = not known
 };
-struct PlanOut { std::vector<int> light, deep; std::vector<int2> heavy; double f_used = 0, limit = 0, total = 0; int nbatch_sub = 0; size_t n_heavy_src = 0; };
+struct PlanOut { std::vector<int> light, deep; std::vector<int2> heavy; double f_used = 0, limit = 0, total = 0; int nbatch_sub = 0; size_t n_heavy_src = 0, n_queue_cut = 0; };
 static void plan_tasks(const PlanIn& in, PlanOut& o)
 {
-    o.light.clear(); o.heavy.clear(); o.deep.clear(); o.f_used = 0; o.limit = 0; o.nbatch_sub = 0; o.n_heavy_src = 0;
+    o.light.clear(); o.heavy.clear(); o.deep.clear(); o.f_used = 0; o.limit = 0; o.nbatch_sub = 0; o.n_heavy_src = 0; o.n_queue_cut = 0;
     double total = 0;
     for (size_t k = 0; k < in.n; k++) total += in.cost[(size_t)in.list[k]];
     o.total = total;
     if (!(in.heavy_div > 0) || !(total > 0)) { o.light.assign(in.list, in.list + in.n); return; }
     double hd = in.heavy_div * (in.measured ? 1.0 : 4.0);
-    if (in.f_last > 0 && in.q_fill > 0 && in.G_last > 0) {
+    bool own_queues = false;
+    if (in.q48 && in.cap > 0) for (size_t k = 0; k < in.n && !own_queues; k++) own_queues = in.q48[(size_t)in.list[k]] > 0;
+    if (!own_queues && in.f_last > 0 && in.q_fill > 0 && in.G_last > 0) {
         const double f_max = in.f_last * 0.8 / in.q_fill * (double)in.G_last / (double)in.G;
         if (1.0 / hd > f_max) hd = 1.0 / f_max;
     }
@@ -985,11 +1012,15 @@ static void plan_tasks(const PlanIn& in, PlanOut& o)
     const bool no_deep = in.no_deep || (in.measured && total / (double)in.waves / (double)std::max(1, in.nbatch) < in.deep_min);
     std::vector<std::pair<double, int>> hv;
     double dsum = 0;
+    // sectors per task the queue of source i allows (0: not even one)
+    auto g_queue = [&](int i) { int g = in.G; if (own_queues) { const double q = in.q48[(size_t)i]; while (g > 0 && q * g / 48.0 > 0.8 * in.cap) g >>= 1; } return g; };
     for (size_t k = 0; k < in.n; k++) {
         const int i = in.list[k];
         const double v = in.cost[(size_t)i];
-        if (v / 48.0 > limit && !no_deep) { o.deep.push_back(i); dsum += v; }
-        else if (v * in.G / 48.0 > limit) hv.push_back({v, i});
+        const int gq = g_queue(i);
+        if (gq < in.G) o.n_queue_cut++;
+        if ((v / 48.0 > limit && !no_deep) || (gq == 0 && !in.no_deep)) { o.deep.push_back(i); dsum += v; }
+        else if (v * in.G / 48.0 > limit || gq < in.G) hv.push_back({v, i});
         else o.light.push_back(i);
     }
     // the deep sources' share of the records decides how many batches their sub-tree launches need (deposit log)
@@ -997,7 +1028,7 @@ static void plan_tasks(const PlanIn& in, PlanOut& o)
     std::stable_sort(hv.begin(), hv.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
     o.n_heavy_src = hv.size();
     for (auto& h : hv) {
-        int Gi = in.G;
+        int Gi = std::max(1, g_queue(h.second));
         while (Gi > 1 && h.first * Gi / 48.0 > limit) Gi >>= 1;
         for (int s0 = 0; s0 < 48; s0 += Gi) o.heavy.push_back(make_int2(h.second, s0 | (Gi << 8)));
     }
@@ -1005,12 +1036,12 @@ static void plan_tasks(const PlanIn& in, PlanOut& o)
 
 // cls[k] of source k: 0 light, -1 deep, else the sectors per task of a heavy source. Returns the number of explicit heavy tasks.
 extern "C" int drt_plan_tasks(const double* cost, int64_t n, int32_t waves, int32_t G, int32_t nbatch, double heavy_div, double deep_min,
-                              int32_t measured, double f_last, double q_fill, int32_t G_last, int32_t* cls, double* limit_out)
+                              int32_t measured, double f_last, double q_fill, int32_t G_last, const double* q48, double cap, int32_t* cls, double* limit_out)
 {
     if (!cost || !cls || n < 0 || waves < 1 || (G != 1 && G != 2 && G != 4 && G != 8 && G != 16)) return DRT_E_ARG;
     std::vector<int> list((size_t)n);
     for (int64_t k = 0; k < n; k++) list[(size_t)k] = (int)k;
-    PlanIn in{list.data(), (size_t)n, cost, waves, G, std::max(1, (int)nbatch), heavy_div, deep_min, measured != 0, false, f_last, q_fill, G_last};
+    PlanIn in{list.data(), (size_t)n, cost, waves, G, std::max(1, (int)nbatch), heavy_div, deep_min, measured != 0, false, f_last, q_fill, G_last, q48, cap};
     PlanOut o;
     plan_tasks(in, o);
     for (int64_t k = 0; k < n; k++) cls[k] = -2;
@@ -1060,11 +1091,15 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool 
     // Otherwise a prior, sqrt(luminosity), scaled to the measured ones if there are any: log cost against log luminosity
     // is a line of slope 0.5-0.9 with correlation 0.91-0.98 on the bench grid. Only ratios of these numbers are used.
     if (!iobs && !psrc && c->d_src_cost) {
-        std::vector<double> meas((size_t)N);
-        HIPCHK(c, hipMemcpy(meas.data(), c->d_src_cost, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> meas(2 * (size_t)N);
+        HIPCHK(c, hipMemcpy(meas.data(), c->d_src_cost, 2 * (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
         c->src_pred_h.assign((size_t)N, 0.0);
         if (c->cost_lum_h.size() != (size_t)N) c->cost_lum_h.assign((size_t)N, 0.0);
         const bool same_kind = (c->cost_kind == rt_type);
+        // queue lengths: a source's own, whichever rank measured it (every source is traced by one rank, so the sum over the ranks
+        // is the value and an unsummed array holds the value or nothing); a source run as sub-tree tasks keeps its last one
+        if (c->src_q_h.size() != (size_t)N || !same_kind) c->src_q_h.assign((size_t)N, 0.0);
+        if (same_kind) for (size_t i = 0; i < (size_t)N; i++) if (meas[(size_t)N + i] > 0) c->src_q_h[i] = meas[(size_t)N + i];
         double sum_meas = 0, sum_prior = 0;
         std::vector<double> lum(list.size());
         for (size_t k = 0; k < list.size(); k++) {
@@ -1259,7 +1294,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     c->cnt.sources = (int64_t)list.size();
     c->cnt.kernel_ms = 0; c->cnt.launches = 0; c->cnt.heavy_tasks = 0; c->cnt.deep_sources = 0; c->cnt.retries = 0;
     const bool cell_stage = !(rt_type == DRT_RTT_PRECALC_SRC || rt_type == DRT_RTT_DIR_SRC);
-    if (cell_stage) HIPCHK(c, hipMemset(c->d_src_cost, 0, (size_t)c->N * sizeof(double)));  // build_src_list has read the previous launch's
+    if (cell_stage) HIPCHK(c, hipMemset(c->d_src_cost, 0, 2 * (size_t)c->N * sizeof(double)));  // build_src_list has read the previous launch's
     // psel_av: a cell stage starts from zero; the point-source stage that follows it writes its own entries [N, N + nsrc) beside the
     // cells' (one rt_mpi reduces both, psel_av_arr(.., iterations, sid) has one row for both, rt_routines.f90:1460). Done BEFORE the
     // empty-list return: a rank without sources of its own (fewer emitting cells than ranks) still takes part in rt_mpi's
@@ -1538,13 +1573,14 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             // cut at 1/32, fills 52 % of the queues; the second, measured, would be cut at 1/8, overflow and be repeated - at 1/20 it
             // goes through.
             PlanIn in{list.data(), list.size(), c->src_pred_h.data(), c->waves, Gbase, nbatch, heavy_div, deep_min, c->pred_measured,
-                      getenv("DRT_NO_DEEP") != nullptr, c->f_last[rt_type & 15], c->q_fill[rt_type & 15], c->G_last[rt_type & 15]};
+                      getenv("DRT_NO_DEEP") != nullptr, c->f_last[rt_type & 15], c->q_fill[rt_type & 15], c->G_last[rt_type & 15],
+                      getenv("DRT_NO_SRC_QUEUES") ? nullptr : c->src_q_h.data(), (double)queue_cap(c, max_blocks * 4, Gbase)};
             PlanOut o;
             plan_tasks(in, o);
             light.swap(o.light); heavy.swap(o.heavy); deep.swap(o.deep);
             nbatch_sub = o.nbatch_sub;
             f_used = o.f_used;
-            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d)\n", rt_type, o.total, o.total / c->waves, o.limit, list.size(), deep.size(), o.n_heavy_src, light.size(), Gbase);
+            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d; %zu cut by their queues, %d rays per queue)\n", rt_type, o.total, o.total / c->waves, o.limit, list.size(), deep.size(), o.n_heavy_src, light.size(), Gbase, o.n_queue_cut, (int)in.cap);
         };
         for (;;) {
             plan(Gtry);
@@ -1563,7 +1599,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (!light.empty()) HIPCHK(c, hipMemcpy(c->d_src_list, light.data(), light.size() * sizeof(int), hipMemcpyHostToDevice));
             c->cnt.heavy_tasks = (int64_t)heavy.size(); c->cnt.deep_sources = (int64_t)deep.size();
             if ((rc = copy_state(true))) return rc;
-            HIPCHK(c, hipMemsetAsync(c->d_src_cost, 0, (size_t)c->N * sizeof(double), 0));
+            HIPCHK(c, hipMemsetAsync(c->d_src_cost, 0, 2 * (size_t)c->N * sizeof(double), 0));
             if (a.psel_sum) {
                 HIPCHK(c, hipMemsetAsync(c->d_psel_sum, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
                 HIPCHK(c, hipMemsetAsync(c->d_psel_cnt, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
@@ -1806,7 +1842,7 @@ extern "C" int drt_rt_mpi(drt_ctx* c, int32_t rt_type)
     } else return fail(c, DRT_E_ARG, "drt_rt_mpi: rt_type %d has no reduction (io_routines.f90:3697)", rt_type);
     // not in the reference: the wave time per cell source of the stage's cell launch, known to the rank that traced it, for
     // every rank's next deal (build_src_list)
-    if ((rc = allreduce_sum(c, c->d_src_cost, (size_t)c->N))) return rc;
+    if ((rc = allreduce_sum(c, c->d_src_cost, 2 * (size_t)c->N))) return rc;   // costs and queue lengths
     c->cost_synced = true;
     if (c->psel_av && rt_type != DRT_RTT_PRECALC_SRC) {  // reduce_psel_av_arr (io_routines.f90:3859-3881); sums and counts, a source's tasks may be spread over ranks here
         // every rank issues these two collectives or none does: the condition is the flag alone (drt_rt_loop allocates and
@@ -1949,6 +1985,7 @@ extern "C" int drt_device_ptr(drt_ctx* c, int32_t which, int32_t il, void** dev_
     double* d; size_t n, rows, cols, stride; int rc;
     if ((rc = field_ptr(c, which, il, &d, &n, &rows, &cols, &stride))) return rc;
     *dev_ptr = d; *count = rows ? rows * stride : n;  // scaspe arrays: the padded device array (the padding stays zero)
+    if (which == DRT_A_SRC_COST) *count = 2 * n;      // the costs and, behind them, the queue lengths: one sum over the ranks for both
     return DRT_OK;
 }
 

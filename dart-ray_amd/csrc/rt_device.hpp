@@ -76,7 +76,8 @@ struct DevProblem {
     unsigned long long* counters;
     int* error;
     int* task_counter;
-    double* src_cost;          // [N]: shader-clock cycles the waves spent on each source's tasks in this launch (steers the next one)
+    double* src_cost;          // [2N]: shader-clock cycles the waves spent on each source's tasks in this launch (steers the next one);
+                               // [N + cell]: the longest ray queue among the source's tasks, scaled to 48 sectors per task
     // Direction tables built on the HOST with the host libm (see build_dir_tables in dartray_rt.hip):
     // per HEALPix level k (nside = 2^k) ring table [4*nside][3] = (theta, sin, cos) indexed by ring jr,
     // and azimuth tables [..][3] = (phi, sin, cos): kshift=0 rows at 2*nr*(nr-1) + jp-1, kshift=1 rows

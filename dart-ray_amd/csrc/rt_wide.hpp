@@ -985,6 +985,7 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
         const ListView LW = list_view(abase, lbytes, a.cap, LP, 2);
         const ListView ST = list_view(abase, lbytes, a.cap, LP, 3);
         int nH = Gt, nL = 0, level = 4;
+        int qt = 0;   // the longest queue of this task
         if (!from_spawn) {
             if (lane < Gt) {
                 Hc.ipix[lane] = (uint32_t)(sec0 + lane);  // idir*4 + idir2 at nside 2
@@ -1050,7 +1051,7 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
                 }
             }
             nH = n_oh;
-            qhi = max(qhi, max(nH, nL));
+            qt = max(qt, max(nH, nL));
             // define_next_level (rt_routines.f90:2745-2770)
             if (nH > 0) level *= 2;
             else if (nL > 0) level /= 2;
@@ -1080,7 +1081,14 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
             wc.psel_n = 0;
             wave_fence();
         }
-        if (a.record_cost && lane == 0) atomicAdd(&P.src_cost[nc], (double)(__builtin_amdgcn_s_memtime() - t_task));
+        qhi = max(qhi, qt);
+        if (a.record_cost && lane == 0) {
+            atomicAdd(&P.src_cost[nc], (double)(__builtin_amdgcn_s_memtime() - t_task));
+            // the queue a task of all 48 sectors of this source would have held, going by this one (the order of non-negative
+            // doubles is the order of their bit patterns); sub-tree tasks say nothing about whole sectors
+            if (!from_spawn && a.export_level == 0)
+                atomicMax((unsigned long long*)&P.src_cost[(unsigned long long)P.N + nc], (unsigned long long)__double_as_longlong((double)qt * 48.0 / (double)Gt));
+        }
         if (sizeof(DRT_WIDE_CNT_T) < 8 && __ballot(((wc.inter | wc.lamdep | wc.slots) >> 30) != 0)) flush_counters();
         err = wave_or(err);
         if (err) break;

@@ -121,7 +121,7 @@ def lib():
         if hasattr(L, "drt_deal_by_cost"):
             L.drt_deal_by_cost.argtypes = [dp, C.c_int64, i32, i32, ip]
         if hasattr(L, "drt_plan_tasks"):
-            L.drt_plan_tasks.argtypes = [dp, C.c_int64, i32, i32, i32, C.c_double, C.c_double, i32, C.c_double, C.c_double, i32, ip, dp]
+            L.drt_plan_tasks.argtypes = [dp, C.c_int64, i32, i32, i32, C.c_double, C.c_double, i32, C.c_double, C.c_double, i32, dp, C.c_double, ip, dp]
         _lib = L
     return _lib
 
@@ -139,13 +139,16 @@ def arena_carve(arena_bytes: int, waves: int, lp: int):
 
 
 def plan_tasks(cost, waves: int, G: int, nbatch: int = 1, heavy_div: float = 8.0, deep_min: float = 4.0e6, measured: bool = True,
-               f_last: float = 0.0, q_fill: float = 0.0, G_last: int = 0):
+               f_last: float = 0.0, q_fill: float = 0.0, G_last: int = 0, q48=None, cap: float = 0.0):
     """drt_plan_tasks: (cls, number of explicit heavy tasks, limit). cls[k] = 0 light, -1 deep, else sectors per task. Needs no GPU."""
     cost = np.ascontiguousarray(cost, dtype=np.float64)
     cls = np.empty(cost.size, dtype=np.int32)
     lim = C.c_double()
+    if q48 is not None:
+        q48 = np.ascontiguousarray(q48, dtype=np.float64)
+        assert q48.size == cost.size
     rc = lib().drt_plan_tasks(_dp(cost), cost.size, waves, G, nbatch, heavy_div, deep_min, 1 if measured else 0, f_last, q_fill, G_last,
-                              cls.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(lim))
+                              _dp(q48) if q48 is not None else None, cap, cls.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(lim))
     if rc < 0:
         raise ValueError(f"drt_plan_tasks: {rc}")
     return cls, rc, lim.value

@@ -64,7 +64,10 @@ extern "C" {
 #define DRT_A_PSEL_CNT 16
 #define DRT_A_SRC_COST 13  /* [tot_ncell] no reference counterpart: wave cycles spent on each cell source in the last cell-source
                             * rt_loop (zero elsewhere). Steers the task order / rank shares of the next one; with np_mpi > 1 it
-                            * is summed over the ranks in rt_mpi like the fields (every source is traced by exactly one rank). */
+                            * is summed over the ranks in rt_mpi like the fields (every source is traced by exactly one rank).
+                            * drt_device_ptr hands out 2 * tot_ncell values: behind the costs lie the sources' queue lengths (the
+                            * longest ray queue among a source's tasks, scaled to 48 sectors per task; the next launch cuts its
+                            * tasks by them), to be summed over the ranks with them. */
 
 /* rt_algorithm_ID (rt_routines.f90:232-250) as far as it changes the path: the stellar-emission run, and the i_obs algorithm
  * (dartray_i_obs, dartray_hub.f90:125-168: observer passes for new directions from a stored scaspe_tot) */
@@ -200,9 +203,11 @@ int drt_reset_counters(drt_ctx *ctx);
  * persistent wavefronts at `G` sectors per task (see plan_tasks in dartray_rt.hip): cls[k] = 0 light (G sectors per task), -1 deep
  * (sub-tree tasks), else the sectors per task of a heavy source; returns the number of explicit heavy tasks, *limit = the largest
  * cost a task may have. measured: the costs are measured wave times (else the prior); f_last / q_fill / G_last: task limit,
- * queue fill and sectors of the stage's last launch (0: none). */
+ * queue fill and sectors of the stage's last launch (0: none); q48 (may be NULL) / cap: the sources' own queue lengths at 48
+ * sectors per task (0: not known) and the rays a queue holds. */
 int drt_plan_tasks(const double *cost, int64_t n, int32_t waves, int32_t G, int32_t nbatch, double heavy_div, double deep_min,
-                   int32_t measured, double f_last, double q_fill, int32_t G_last, int32_t *cls, double *limit);
+                   int32_t measured, double f_last, double q_fill, int32_t G_last, const double *q48, double cap, int32_t *cls,
+                   double *limit);
 
 /* Introspection (no GPU needed): how an arena of `arena_bytes` is split among `waves` wavefronts carrying `lp`
  * (a power of two >= lnum) luminosities per ray: queue depth `cap`, hash size `hcap`, bytes per wave `stride`, and the

@@ -193,7 +193,8 @@ def test_plan_tasks_rules(pkg):
     one class; a light source's task (G sectors) and a heavy source's tasks (Gi sectors, a power-of-two fraction of G) stay under
     the limit unless Gi is already 1; the explicit heavy tasks cover each heavy source's 48 sectors once; deep = one sector alone
     exceeds the limit; a launch planned from the prior is cut four times finer; the limit is never coarser than the queues of
-    the stage's last launch allow; and no source is deep in a short, measured launch."""
+    the stage's last launch allow; no source is deep in a short, measured launch; and where the sources' own queue lengths are known
+    they bound the sectors per task."""
     rng = np.random.default_rng(5)
     n, waves, G = 5000, 3072, 16
     cost = np.exp(rng.normal(0.0, 1.6, n)) * 1e7            # wave cycles, spread over three decades
@@ -229,6 +230,27 @@ def test_plan_tasks_rules(pkg):
     # batches (deposit log): every launch is 1/nbatch of the work
     _, _, lim_b = pkg.host.plan_tasks(cost, waves, G, nbatch=6, heavy_div=8.0, deep_min=0.0, measured=True)
     assert lim_b == pytest.approx(limit / 6.0, rel=1e-12)
+    # the sources' own queues (q48: the queue a 48-sector task of the source would hold; cap rays fit a queue): a source takes the
+    # sectors per task that keep its queue under 0.8 cap - whatever its cost - and is deep where one sector does not; the rule on
+    # the last launch's one queue is then not applied; sources whose queue is not known are cut by cost alone
+    cap = 4000.0
+    q48 = np.exp(rng.normal(np.log(6000.0), 1.0, n)); q48[::7] = 0.0; q48[5:10] = 1e6
+    cls_q, ntask_q, lim_own = pkg.host.plan_tasks(cost, waves, G, heavy_div=8.0, deep_min=10 * per_wave, measured=True, f_last=1 / 32, q_fill=0.52, G_last=8,
+                                                  q48=q48, cap=cap)
+    assert lim_own == pytest.approx(limit, rel=1e-12)
+    known = q48 > 0
+    assert (cls_q[5:10] == -1).all()                                         # one sector would overflow: sub-tree tasks, however short the launch
+    deep_q = cls_q == -1
+    assert (q48[deep_q] / 48.0 > 0.8 * cap).all()
+    g_eff = np.where(cls_q == 0, G, cls_q)
+    ok = ~deep_q
+    assert (q48[ok] * g_eff[ok] / 48.0 <= 0.8 * cap).all()
+    assert ((cost[ok] * g_eff[ok] / 48.0 <= limit) | (g_eff[ok] == 1)).all()
+    finer = ok & (g_eff < G)                                                 # and no finer than one of the two rules asks
+    g2 = np.minimum(2 * g_eff, G)
+    assert ((q48 * g2 / 48.0 > 0.8 * cap) | (cost * g2 / 48.0 > limit))[finer].all()
+    assert np.array_equal(cls_q[~known], cls_s[~known])
+    assert ntask_q == int((48 // cls_q[cls_q > 0]).sum())
     # heavy_div = 0 switches the cutting off
     cls0, n0, _ = pkg.host.plan_tasks(cost, waves, G, heavy_div=0.0)
     assert (cls0 == 0).all() and n0 == 0

@@ -1014,3 +1014,25 @@ def test_bench_grid_sample_of_sources_matches_oracle(pkg, tmp_path, monkeypatch)
         a, b = g.scaspe(il), np.array(o.scaspe(il))
         assert relmax(a, b) <= RTOL and relelem(a, b) <= RTOL_ELEM, il
     g.close(); o.close()
+
+
+def test_a_repeated_stage_is_not_undone_again(pkg):
+    """Queue-aware planning (plan_tasks, CNT_QMAX): once a kind of stage has run, its next launches are sized by the longest ray
+    queue the last one held - sectors per task and task limit grow only where that queue left room. On TRUST-I tau = 1 with 32
+    wavelengths (21 801 cells) and the default 16 GiB arena the scattering step is repeated three times: whatever the first,
+    unmeasured call needs, calls two and three must go through without an undone attempt, and all three trace the same rays."""
+    case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=4, wavelengths=list(range(32)), max_sca_iterations=1)
+    g = pkg.DartRayGPU(case)
+    g.rt_prepare("start")
+    g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+    g.rt_prepare("prep_part2")
+    g.rt_loop("dir_cell"); g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+    assert not g.scatt_prepare()
+    seen = []
+    for k in range(3):
+        g.reset_counters(); g.rt_loop("scatt")
+        c = g.counters()
+        seen.append((c["intersections"], c["rays"], c["deposits"], c["retries"], c["launches"]))
+    assert seen[0][:3] == seen[1][:3] == seen[2][:3], seen
+    assert seen[1][3] == 0 and seen[2][3] == 0, seen
+    g.close()
