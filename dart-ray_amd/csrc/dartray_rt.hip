@@ -1098,7 +1098,7 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool 
         const bool same_kind = (c->cost_kind == rt_type);
         // queue lengths: a source's own, whichever rank measured it (every source is traced by one rank, so the sum over the ranks
         // is the value and an unsummed array holds the value or nothing); a source run as sub-tree tasks keeps its last one
-        if (c->src_q_h.size() != (size_t)N || !same_kind) c->src_q_h.assign((size_t)N, 0.0);
+        if (c->src_q_h.size() != (size_t)N || (launching && !same_kind)) c->src_q_h.assign((size_t)N, 0.0);   // (a query, drt_get_sources, forgets nothing)
         if (same_kind) for (size_t i = 0; i < (size_t)N; i++) if (meas[(size_t)N + i] > 0) c->src_q_h[i] = meas[(size_t)N + i];
         double sum_meas = 0, sum_prior = 0;
         std::vector<double> lum(list.size());
