@@ -85,7 +85,7 @@ struct drt_ctx {
                            // kind since round 3: the direct light of the N-body grid overflows at 8 sectors, its scattering
                            // iterations fill a tenth of their queues at 4 and were held there by the one global value
     // per rt_type: sectors per task of the stage's last successful cell launch and the share of the queue capacity its longest
-    // queue took (CNT_QMAX / cap): more sectors are tried only where that leaves room (queues grow with the sectors of a task)
+    // queue took (from the sources' queue lengths): more sectors are tried only where that leaves room (queues grow with the sectors of a task)
     int G_last[16] = {0};
     double q_fill[16] = {0.0};
     double f_last[16] = {0.0};   // ... and the task limit of that launch as a fraction of a wave's share of the stage (1 / hd in plan())
@@ -1355,7 +1355,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     bool ovf_log = false;
     int g_used = 0;   // sectors per task of the cell launch that went through
     double f_used_stage = 0.0;   // and its task limit as a fraction of a wave's share
-    HIPCHK(c, hipMemsetAsync(c->d_counters + CNT_QMAX, 0, sizeof(unsigned long long), 0));
+    double qmax_stage = 0.0;   // the longest ray queue of the cell launch that went through
     a.psel_sum = nullptr; a.psel_cnt = nullptr;
     if (c->psel_av) { a.psel_sum = c->d_psel_sum; a.psel_cnt = c->d_psel_cnt; }
     // Phase window (trace_items_w): 1.5 cell sizes where deposits dominate; off where a source launches few rays (the
@@ -1540,11 +1540,17 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // previous call of the same stage (a run repeats its scattering stage); first call: 8.
         int Gtry = c->G_want[rt_type & 15] > 0 ? c->G_want[rt_type & 15] : 8;
         if (const char* e = getenv("DRT_SECTORS_WANT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) Gtry = v; }   // developer knob: overrides the choice by work per source
-        if (c->G_cell[rt_type & 15] > 0) Gtry = std::min(Gtry, c->G_cell[rt_type & 15]);
+        // the sources' own queue lengths (src_q_h, plan_tasks) make both memories below unnecessary: each source is cut by its own
+        // queue, so the stage goes for the sectors it wants (bench grid with the default 16 GiB arena: the first call had ended at one
+        // sector per task on an eighth of the waves and every later call stayed at one sector, 4.77 s per step)
+        size_t q_known = 0;
+        if (!getenv("DRT_NO_SRC_QUEUES") && c->src_q_h.size() == (size_t)c->N) for (int i : list) q_known += c->src_q_h[(size_t)i] > 0;
+        const bool own_queues = 2 * q_known >= list.size() && !list.empty();   // (build_src_list forgets them when the kind of stage changes)
+        if (c->G_cell[rt_type & 15] > 0 && !own_queues) Gtry = std::min(Gtry, c->G_cell[rt_type & 15]);
         // more sectors per task than the stage's last launch took: only if its queues left the room (bench grid, 32 wavelengths:
         // the launch at 8 sectors fills 60-70 % of the queues of a 200 GiB arena; trying 16 meant an overflow, an undone attempt
         // of 3.4 s and a repeat at 8 - in the second call of every stage)
-        if (c->G_last[rt_type & 15] > 0 && !getenv("DRT_SECTORS_WANT"))
+        if (c->G_last[rt_type & 15] > 0 && !getenv("DRT_SECTORS_WANT") && !own_queues)
             while (Gtry > c->G_last[rt_type & 15] && c->q_fill[rt_type & 15] * (double)Gtry / (double)c->G_last[rt_type & 15] > 0.85) Gtry /= 2;
         double f_used = 0.0;
         Gtry = std::min(Gtry, G);
@@ -1581,6 +1587,23 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             nbatch_sub = o.nbatch_sub;
             f_used = o.f_used;
             if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d; %zu cut by their queues, %d rays per queue)\n", rt_type, o.total, o.total / c->waves, o.limit, list.size(), deep.size(), o.n_heavy_src, light.size(), Gbase, o.n_queue_cut, (int)in.cap);
+        };
+        bool kept_once = false;
+        // The kernel leaves, per source, the longest queue among its whole-sector tasks (second half of src_cost). All tasks of a
+        // source take the same number of sectors - the plan's - so the host turns the array into "queue at 48 sectors per task",
+        // the form the planner, the other ranks (the array is summed over the ranks with the costs) and the next call use.
+        // Returns the longest queue itself.
+        auto scale_queues = [&](int Gl, double& qmax) -> int {
+            qmax = 0.0;
+            if (heavy.size() + light.size() + deep.size() == 0) return DRT_OK;
+            std::vector<double> qh((size_t)c->N);
+            HIPCHK(c, hipMemcpy(qh.data(), c->d_src_cost + c->N, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost));
+            for (int i : deep) qh[(size_t)i] = 0.0;   // sub-tree tasks say nothing about whole sectors: these sources keep what is known of them
+            for (int i : light) { qmax = std::max(qmax, qh[(size_t)i]); qh[(size_t)i] *= 48.0 / Gl; }
+            int last = -1;
+            for (const int2& h : heavy) if (h.x != last) { last = h.x; qmax = std::max(qmax, qh[(size_t)h.x]); qh[(size_t)h.x] *= 48.0 / (h.y >> 8); }   // a source's tasks are listed together
+            HIPCHK(c, hipMemcpy(c->d_src_cost + c->N, qh.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice));
+            return DRT_OK;
         };
         for (;;) {
             plan(Gtry);
@@ -1635,12 +1658,25 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 continue;
             }
             c->overflow_met = true;
+            // what the undone launch learnt about queues: the tasks that were running when it stopped finished and left their sources'
+            // queue lengths, the ones that overflowed a bound (rt_stage_wide). The repeat cuts those sources by them; the first
+            // repeat of a call keeps the sectors per task for all the others.
+            bool learnt = false;
+            if (!getenv("DRT_NO_SRC_QUEUES") && c->src_q_h.size() == (size_t)c->N) {
+                double qm;
+                if ((rc = scale_queues(Gtry, qm))) return rc;
+                std::vector<double> qh((size_t)c->N);
+                HIPCHK(c, hipMemcpy(qh.data(), c->d_src_cost + c->N, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < (size_t)c->N; i++) if (qh[i] > c->src_q_h[i]) { c->src_q_h[i] = qh[i]; learnt = true; }
+            }
+            if (learnt && !kept_once) { kept_once = true; continue; }
             if (Gtry > 1) Gtry /= 2;                  // shorter queues first,
             else if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;  // then fewer waves with deeper ones
             else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
         if (c->overflow_met) c->G_cell[rt_type & 15] = c->G_cell[rt_type & 15] > 0 ? std::min(c->G_cell[rt_type & 15], Gtry) : Gtry;  // an overflow was met: more sectors than this do not fit this arena
         g_used = Gtry; f_used_stage = f_used;
+        if ((rc = scale_queues(Gtry, qmax_stage))) return rc;
         c->overflow_met = false;
     }
     HIPCHK(c, hipGetLastError());
@@ -1657,8 +1693,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
     if ((rc = check_device_error(c))) return rc;
     if ((rc = pull_counters(c))) return rc;
     if (!psrc && g_used > 0 && c->cap > 0) {
-        unsigned long long qmax = 0;
-        HIPCHK(c, hipMemcpy(&qmax, c->d_counters + CNT_QMAX, sizeof qmax, hipMemcpyDeviceToHost));
+        const unsigned long long qmax = (unsigned long long)(qmax_stage + 0.5);
         c->G_last[rt_type & 15] = g_used;
         c->q_fill[rt_type & 15] = (double)qmax / (double)c->cap;
         c->f_last[rt_type & 15] = f_used_stage;

@@ -25,7 +25,7 @@ enum { ERR_NEG_LENGTH = 1, ERR_CELL_NOT_FOUND = 2, ERR_CAPACITY = 4, ERR_NSIDE =
 // counters[] slots
 enum { CNT_INTERSECTIONS = 0, CNT_RAYS = 1, CNT_DEPOSITS = 2, CNT_SCASPE = 3, CNT_LAMDEP = 4, CNT_UADD = 5, CNT_UREAD = 6, CNT_SCASLOTS = 7,
        CNT_ATOM = 20, CNT_ATOM_LANES = 21,
-       CNT_QMAX = 30,   // the longest ray queue any wave held in the launch (rays): what the next launch's sectors per task are sized by
+       CNT_QMAX = 30,   // (free since round 3: the longest ray queue of a launch is derived from the sources' queue lengths, src_cost[N + cell])
        CNT_N = 32 };    // 8..19, 22..29: phase timers of a -DDRT_PROFILE build
 
 struct DevProblem {

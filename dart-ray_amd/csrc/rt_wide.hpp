@@ -66,7 +66,8 @@ typedef ldouble* iptr_t;
 // + [DRT_OPQ][64] u_final sums of the chunk's wavelengths by leader lane, + 64 ints: the leader lanes in rank order
 // (one wavelength: a chunk of one)
 #define DRT_OPQ_OF(LP) ((LP) == 1 ? 1 : DRT_OPQ)
-#define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ_OF(LP) + 3 + 64 * DRT_OPQ_OF(LP) + 32 + 1)
+// + 1 word: the longest queue of the running task (kept here, not in a register that would be live across the step loop)
+#define DRT_LDS_WORDS(L, LP) (DRT_I_WORDS(L) + (LP) + 5 * DRT_BST + 3 * 64 * DRT_OPQ_OF(LP) + 3 + 64 * DRT_OPQ_OF(LP) + 32 + 1 + 1)
 // waves per SIMD of an instantiation; four for one wavelength (128 registers, 5 KB of LDS per wave) was tried after the register
 // diet of round 2: 585 against 503 ms on the bench grid, 6.1 against 4.9 ms on config 1 - the loop still spills at 128
 #ifndef DRT_WAVES_LP1
@@ -882,6 +883,8 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
     ldouble* ll = (ldouble*)lds_w + wib * DRT_LDS_WORDS(L, LP) + DRT_I_WORDS(L);
     ldouble* bst = ll + LP;  // [5][DRT_BST]: C, U of the wavelength being flushed; nx, ny, nz of every ray;
     ldouble* opq = bst + 5 * DRT_BST;  // [DRT_OPQ][3][64]: dens, aux, intensity of the wavelengths being deposited 
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    lds_u32* const qw = (lds_u32*)(ll + (DRT_LDS_WORDS(L, LP) - DRT_I_WORDS(L) - 1));   // the last word of the wave's area
     char* abase = P.arena + (unsigned long long)gwave * a.wave_stride;
     const unsigned long long lbytes = list_bytes(a.cap, LP);
     const ArenaLayout AL = arena_layout(a.cap, a.hcap, LP);
@@ -904,7 +907,6 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
     WideCounters wc = {};
     int err = 0;
     WaveLog WL = {-1, 0u, 0u};
-    int qhi = 0;   // the longest high / low queue this wave held (wave-uniform)
     TSTAMP(tk0);
     HotP H;
     H.u_pad = (a.scatter && !LOGM) ? 1 : 0;  // log mode: no row atomics for u_final to ride in
@@ -985,7 +987,7 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
         const ListView LW = list_view(abase, lbytes, a.cap, LP, 2);
         const ListView ST = list_view(abase, lbytes, a.cap, LP, 3);
         int nH = Gt, nL = 0, level = 4;
-        int qt = 0;   // the longest queue of this task
+        if (lane == 0) *qw = 0u;   // the longest high / low queue of this task
         if (!from_spawn) {
             if (lane < Gt) {
                 Hc.ipix[lane] = (uint32_t)(sec0 + lane);  // idir*4 + idir2 at nside 2
@@ -1051,7 +1053,7 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
                 }
             }
             nH = n_oh;
-            qt = max(qt, max(nH, nL));
+            if (lane == 0) (void)__hip_atomic_fetch_max(qw, (unsigned)max(nH, nL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             // define_next_level (rt_routines.f90:2745-2770)
             if (nH > 0) level *= 2;
             else if (nL > 0) level /= 2;
@@ -1081,13 +1083,15 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
             wc.psel_n = 0;
             wave_fence();
         }
-        qhi = max(qhi, qt);
         if (a.record_cost && lane == 0) {
             atomicAdd(&P.src_cost[nc], (double)(__builtin_amdgcn_s_memtime() - t_task));
-            // the queue a task of all 48 sectors of this source would have held, going by this one (the order of non-negative
-            // doubles is the order of their bit patterns); sub-tree tasks say nothing about whole sectors
-            if (!from_spawn && a.export_level == 0)
-                atomicMax((unsigned long long*)&P.src_cost[(unsigned long long)P.N + nc], (unsigned long long)__double_as_longlong((double)qt * 48.0 / (double)Gt));
+            // the longest queue among the source's tasks (the order of non-negative doubles is the order of their bit patterns).
+            // The host scales it to 48 sectors per task - it knows how many the source's tasks had - and drops it for the sources
+            // it ran as sub-tree tasks. A task that outgrew its queues (the loop above left with the error in every lane) leaves
+            // a bound instead - three times the capacity, so that the repeated launch cuts it four times finer - read by the host
+            // before it undoes the launch. (No condition on the kind of task here: keeping one alive across the step loop cost
+            // five more scratch loads per step at one wavelength, 558 against 507 ms.)
+            atomicMax((unsigned long long*)&P.src_cost[(unsigned long long)P.N + nc], (unsigned long long)__double_as_longlong((double)((err & ERR_CAPACITY) ? 3u * (unsigned)a.cap : *qw)));
         }
         if (sizeof(DRT_WIDE_CNT_T) < 8 && __ballot(((wc.inter | wc.lamdep | wc.slots) >> 30) != 0)) flush_counters();
         err = wave_or(err);
@@ -1096,7 +1100,6 @@ __device__ __forceinline__ void rt_stage_wide_body(const DevProblem* __restrict_
     flush_counters();
     if constexpr (LOGM) { if (lane == 0 && WL.cur >= 0) a.log_chunk_count[WL.cur] = WL.nidx; }
     if (lane == 0) {
-        atomicMax(&P.counters[CNT_QMAX], (unsigned long long)qhi);
         atomicAdd(&P.counters[CNT_ATOM], wc.atom);
         atomicAdd(&P.counters[CNT_ATOM_LANES], wc.atom_lanes);
 #ifdef DRT_PROFILE
