@@ -77,7 +77,8 @@ struct DevProblem {
     int* error;
     int* task_counter;
     double* src_cost;          // [2N]: shader-clock cycles the waves spent on each source's tasks in this launch (steers the next one);
-                               // [N + cell]: the longest ray queue among the source's tasks, scaled to 48 sectors per task
+                               // [N + cell]: the longest ray queue among the source's tasks, as the kernel leaves it; the host scales it to
+                               // 48 sectors per task after the launch (rt_loop: scale_queues)
     // Direction tables built on the HOST with the host libm (see build_dir_tables in dartray_rt.hip):
     // per HEALPix level k (nside = 2^k) ring table [4*nside][3] = (theta, sin, cos) indexed by ring jr,
     // and azimuth tables [..][3] = (phi, sin, cos): kshift=0 rows at 2*nr*(nr-1) + jp-1, kshift=1 rows
