@@ -115,6 +115,7 @@ struct drt_ctx {
     // being prepared; cost_lum_h[i] = its luminosity (sum over the wavelengths) in the launch d_src_cost was measured in,
     // cost_kind = that launch's rt_type (-1: nothing measured yet)
     std::vector<double> src_pred_h, cost_lum_h;
+    std::vector<double> src_q_est_h;   // [N]: an estimate of the same for sources nothing was measured of (fit_queue_prior, after an undone launch)
     std::vector<double> src_q_h;   // [N]: the longest ray queue a 48-sector task of the source would hold (measured on its tasks of the last launch
                                    // of this kind of stage that ran it as whole sectors; 0 = not known)
     int cost_kind = -1;
@@ -965,6 +966,29 @@ extern "C" int drt_deal_by_cost(const double* cost, int64_t n, int32_t np, int32
     return DRT_OK;
 }
 
+// ---- queue lengths of the sources nothing is known of, from the ones an undone launch measured (pure; drt_fit_queue_prior) -------
+// A source's longest queue grows with its luminosity: log q48 against log luminosity is a line of slope 0.5-1.1 with correlation
+// 0.62-0.95 in the cell-source stages of the BASELINE configurations, 99 % of the sources within a factor 2-4 of it
+// (tools/queue_vs_cost.py). Least squares in the logarithms over the n pairs with q > 0 and lum > 0; slope kept within [0, 1.5].
+// False (nothing to go by) with fewer than 64 pairs or luminosities that are all alike.
+static bool fit_queue_prior(const double* lum, const double* q, size_t n, double& a, double& b)
+{
+    double sx = 0, sy = 0, sxx = 0, sxy = 0; size_t m = 0;
+    for (size_t k = 0; k < n; k++) if (q[k] > 0 && lum[k] > 0) { const double x = log(lum[k]), y = log(q[k]); sx += x; sy += y; sxx += x * x; sxy += x * y; m++; }
+    if (m < 64) return false;
+    const double vx = sxx / m - (sx / m) * (sx / m);
+    if (!(vx > 1e-6)) return false;
+    b = (sxy / m - (sx / m) * (sy / m)) / vx;
+    b = std::min(1.5, std::max(0.0, b));
+    a = sy / m - b * sx / m;
+    return true;
+}
+extern "C" int drt_fit_queue_prior(const double* lum, const double* q, int64_t n, double* a, double* b)
+{
+    if (!lum || !q || !a || !b || n < 0) return DRT_E_ARG;
+    return fit_queue_prior(lum, q, (size_t)n, *a, *b) ? DRT_OK : DRT_E_CAPACITY;
+}
+
 // ---- task planning of a cell-source launch (pure; drt_plan_tasks exposes it for the CPU tests) -----------------------------
 // A task is one wave's serial work: no task may be a large part of its launch. From the expected cost of every source (measured
 // wave time scaled with the luminosity, or the prior sqrt(luminosity)), with limit = (sum of the costs / waves) / hd / nbatch:
@@ -1098,7 +1122,7 @@ static int build_src_list(drt_ctx* c, int rt_type, std::vector<int>& list, bool 
         const bool same_kind = (c->cost_kind == rt_type);
         // queue lengths: a source's own, whichever rank measured it (every source is traced by one rank, so the sum over the ranks
         // is the value and an unsummed array holds the value or nothing); a source run as sub-tree tasks keeps its last one
-        if (c->src_q_h.size() != (size_t)N || (launching && !same_kind)) c->src_q_h.assign((size_t)N, 0.0);   // (a query, drt_get_sources, forgets nothing)
+        if (c->src_q_h.size() != (size_t)N || (launching && !same_kind)) { c->src_q_h.assign((size_t)N, 0.0); c->src_q_est_h.assign((size_t)N, 0.0); }   // (a query, drt_get_sources, forgets nothing)
         if (same_kind) for (size_t i = 0; i < (size_t)N; i++) if (meas[(size_t)N + i] > 0) c->src_q_h[i] = meas[(size_t)N + i];
         double sum_meas = 0, sum_prior = 0;
         std::vector<double> lum(list.size());
@@ -1569,7 +1593,11 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         if (const char* e = getenv("DRT_HEAVY_DIV")) heavy_div = atof(e);
         std::vector<int> light, deep;
         std::vector<int2> heavy;
+        std::vector<double> q_plan;   // a source's measured queue length, else the estimate made after an undone launch, else 0
         auto plan = [&](int Gbase) {
+            q_plan.assign((size_t)c->N, 0.0);
+            if (c->src_q_h.size() == (size_t)c->N)
+                for (int i : list) q_plan[(size_t)i] = c->src_q_h[(size_t)i] > 0 ? c->src_q_h[(size_t)i] : (c->src_q_est_h.size() == (size_t)c->N ? c->src_q_est_h[(size_t)i] : 0.0);
             double deep_min = 4.0e6;   // shader-clock cycles of wave time per wave (~1.7 ms) below which no source is run as sub-tree tasks:
                                        // config 1 (a 2 ms step): 96 deep sources -> 3.37 ms per step, none -> 2.38, with the limit at 1/8
                                        // 2.06; a 5 ms threshold lost the third scattering iteration of an 8-rank run (36.7 against 15.9 ms)
@@ -1580,7 +1608,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             // goes through.
             PlanIn in{list.data(), list.size(), c->src_pred_h.data(), c->waves, Gbase, nbatch, heavy_div, deep_min, c->pred_measured,
                       getenv("DRT_NO_DEEP") != nullptr, c->f_last[rt_type & 15], c->q_fill[rt_type & 15], c->G_last[rt_type & 15],
-                      getenv("DRT_NO_SRC_QUEUES") ? nullptr : c->src_q_h.data(), (double)queue_cap(c, max_blocks * 4, Gbase)};
+                      getenv("DRT_NO_SRC_QUEUES") ? nullptr : q_plan.data(), (double)queue_cap(c, max_blocks * 4, Gbase)};
             PlanOut o;
             plan_tasks(in, o);
             light.swap(o.light); heavy.swap(o.heavy); deep.swap(o.deep);
@@ -1668,6 +1696,17 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 std::vector<double> qh((size_t)c->N);
                 HIPCHK(c, hipMemcpy(qh.data(), c->d_src_cost + c->N, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost));
                 for (size_t i = 0; i < (size_t)c->N; i++) if (qh[i] > c->src_q_h[i]) { c->src_q_h[i] = qh[i]; learnt = true; }
+                // ... and about the sources that had not run yet: twice what the line through (luminosity, queue) of the measured
+                // ones gives (N-body direct light with the default arena: four undone attempts of ~3 s each, every one stopped by
+                // a source the one before had not reached)
+                std::vector<double> xl, yq;
+                for (int i : list) if (c->src_q_h[(size_t)i] > 0) { xl.push_back(c->cost_lum_h[(size_t)i]); yq.push_back(c->src_q_h[(size_t)i]); }
+                double fa = 0, fb = 0;
+                if (!getenv("DRT_NO_QUEUE_PRIOR") && fit_queue_prior(xl.data(), yq.data(), xl.size(), fa, fb)) {
+                    if (c->src_q_est_h.size() != (size_t)c->N) c->src_q_est_h.assign((size_t)c->N, 0.0);
+                    for (int i : list) { const double lum = c->cost_lum_h[(size_t)i]; c->src_q_est_h[(size_t)i] = lum > 0 ? 2.0 * exp(fa + fb * log(lum)) : 0.0; }
+                    if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] rt %d: queue prior from %zu sources: q48 = %.3g * luminosity^%.2f (x 2)\n", rt_type, xl.size(), exp(fa), fb);
+                }
             }
             if (learnt && !kept_once) { kept_once = true; continue; }
             if (Gtry > 1) Gtry /= 2;                  // shorter queues first,

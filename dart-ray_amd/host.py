@@ -47,7 +47,7 @@ EXPORTS = ["drt_create", "drt_destroy", "drt_last_error", "drt_configure", "drt_
            "drt_set_wavelengths", "drt_set_point_sources", "drt_set_observers", "drt_rt_prepare", "drt_rt_loop",
            "drt_rt_loop_iobs", "drt_rt_mpi", "drt_get_array", "drt_set_array", "drt_get_npix", "drt_get_src_cell",
            "drt_device_ptr", "drt_en_lim", "drt_iterations", "drt_cnflag", "drt_calc_sed", "drt_get_counters", "drt_reset_counters",
-           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_comm_selftest", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm", "drt_set_psel_av", "drt_plan_tasks"]
+           "drt_comm_unique_id", "drt_comm_init", "drt_comm_destroy", "drt_comm_selftest", "drt_arena_carve", "drt_get_sources", "drt_mark_cost_reduced", "drt_deal_by_cost", "drt_set_algorithm", "drt_set_psel_av", "drt_plan_tasks", "drt_fit_queue_prior"]
 
 
 def build(force: bool = False) -> str:
@@ -152,6 +152,17 @@ def plan_tasks(cost, waves: int, G: int, nbatch: int = 1, heavy_div: float = 8.0
     if rc < 0:
         raise ValueError(f"drt_plan_tasks: {rc}")
     return cls, rc, lim.value
+
+
+def fit_queue_prior(lum, q):
+    """drt_fit_queue_prior: (a, b) of log q = a + b log lum, or None when there is nothing to fit. Needs no GPU."""
+    lum = np.ascontiguousarray(lum, dtype=np.float64); q = np.ascontiguousarray(q, dtype=np.float64)
+    assert lum.size == q.size
+    L = lib()
+    L.drt_fit_queue_prior.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    a, b = C.c_double(), C.c_double()
+    rc = L.drt_fit_queue_prior(_dp(lum), _dp(q), lum.size, C.byref(a), C.byref(b))
+    return None if rc != 0 else (a.value, b.value)
 
 
 def deal_by_cost(cost, np_mpi: int, chunk: int = 64) -> np.ndarray:

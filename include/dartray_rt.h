@@ -209,6 +209,10 @@ int drt_plan_tasks(const double *cost, int64_t n, int32_t waves, int32_t G, int3
                    int32_t measured, double f_last, double q_fill, int32_t G_last, const double *q48, double cap, int32_t *cls,
                    double *limit);
 
+/* Introspection (no GPU needed): the line log q = a + b log lum through the sources whose longest ray queue q (at 48 sectors per
+ * task) an undone launch measured, by which the queues of the others are estimated (fit_queue_prior in dartray_rt.hip). DRT_OK, or
+ * DRT_E_CAPACITY when fewer than 64 pairs with q > 0 and lum > 0 exist or the luminosities are all alike. */
+int drt_fit_queue_prior(const double *lum, const double *q, int64_t n, double *a, double *b);
 /* Introspection (no GPU needed): how an arena of `arena_bytes` is split among `waves` wavefronts carrying `lp`
  * (a power of two >= lnum) luminosities per ray: queue depth `cap`, hash size `hcap`, bytes per wave `stride`, and the
  * byte offsets of the regions of one wave's slice: 4 ray queues, hash keys, hash members, status words, HG

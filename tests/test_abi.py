@@ -254,3 +254,26 @@ def test_plan_tasks_rules(pkg):
     # heavy_div = 0 switches the cutting off
     cls0, n0, _ = pkg.host.plan_tasks(cost, waves, G, heavy_div=0.0)
     assert (cls0 == 0).all() and n0 == 0
+
+
+def test_fit_queue_prior(pkg):
+    """drt_fit_queue_prior (fit_queue_prior in dartray_rt.hip, pure): the line through (log luminosity, log queue length) of the sources
+    an undone launch measured; pairs without a measurement are ignored; the slope stays within [0, 1.5]; nothing is fitted from fewer
+    than 64 pairs or from luminosities that are all alike."""
+    rng = np.random.default_rng(11)
+    n = 4000
+    lum = np.exp(rng.normal(70.0, 2.0, n))
+    q = 3.0 * lum ** 0.7 * np.exp(rng.normal(0.0, 0.3, n))
+    q[::3] = 0.0                                              # not measured
+    a, b = pkg.host.fit_queue_prior(lum, q)
+    assert b == pytest.approx(0.7, abs=0.02) and a == pytest.approx(np.log(3.0), abs=1.5)
+    ok = q > 0
+    pred = np.exp(a + b * np.log(lum[ok]))
+    assert np.median(q[ok] / pred) == pytest.approx(1.0, abs=0.05)
+    assert (q[ok] <= 2.0 * pred).mean() > 0.97               # what the launch plans with: twice the line
+    _, b_hi = pkg.host.fit_queue_prior(lum, lum ** 3.0)
+    assert b_hi == 1.5
+    _, b_lo = pkg.host.fit_queue_prior(lum, lum ** -1.0)
+    assert b_lo == 0.0
+    assert pkg.host.fit_queue_prior(lum[:63], q[:63] + 1.0) is None
+    assert pkg.host.fit_queue_prior(np.full(200, 5.0), np.full(200, 7.0)) is None

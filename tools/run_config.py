@@ -35,7 +35,7 @@ def stage(name, fn):
     gpu.reset_counters(); ts = time.time(); fn(); c = gpu.counters()
     tot["inter"] += c["intersections"]; tot["ms"] += c["kernel_ms"]
     print(f"  {name:12s} {c['kernel_ms']:10.1f} ms  sources {c['sources']:8d} intersections {c['intersections']:14d} "
-          f"{c['intersections'] / max(c['kernel_ms'], 1e-9) * 1e3:.3e}/s", flush=True)
+          f"{c['intersections'] / max(c['kernel_ms'], 1e-9) * 1e3:.3e}/s  launches {c['launches']} undone {c['retries']}", flush=True)
 gpu.rt_prepare("start")
 stage("precalc_cell", lambda: gpu.rt_loop("precalc_cell")); stage("precalc_src", lambda: gpu.rt_loop("precalc_src")); gpu.rt_mpi("precalc_src")
 gpu.rt_prepare("prep_part2")
