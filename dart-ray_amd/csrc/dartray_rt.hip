@@ -128,7 +128,8 @@ struct drt_ctx {
     DevProblem* d_prob = nullptr;
     DevProblem hprob{};
     char* d_arena = nullptr;
-    size_t arena_bytes = 16ull << 30;
+    size_t arena_bytes = 0;   // 0: not configured - sized at allocation from the wavelengths per ray and the device (default_arena_bytes)
+    bool arena_auto = true; int arena_lp = 0;
     int waves = 0, cap = 0, hcap = 0;
     unsigned long long wave_stride = 0;
     unsigned long long* d_counters = nullptr;
@@ -270,7 +271,7 @@ extern "C" const char* drt_last_error(const drt_ctx* c) { return c ? c->err.c_st
 extern "C" int drt_configure(drt_ctx* c, size_t arena_bytes, int waves)
 {
     if (!c) return DRT_E_ARG;
-    if (arena_bytes) c->arena_bytes = arena_bytes;
+    if (arena_bytes) { c->arena_bytes = arena_bytes; c->arena_auto = false; }
     if (waves > 0) c->waves = waves;
     for (int k = 0; k < 16; k++) c->G_cell[k] = 0;
     if (c->d_arena) { (void)hipFree(c->d_arena); c->d_arena = nullptr; }
@@ -600,6 +601,22 @@ template <int LP, int MODE> static int wide_blocks_per_cu_(drt_ctx* c)
 // the smallest of the instantiations' answers (0: rows by atomics, 1: with the memory-table path, 2: deposit log): the arena is carved once for all
 template <int LP> static int wide_blocks_per_cu(drt_ctx* c) { return std::min(wide_blocks_per_cu_<LP, 0>(c), std::min(wide_blocks_per_cu_<LP, 1>(c), wide_blocks_per_cu_<LP, 2>(c))); }
 
+// The queue arena of a context that was not given one (drt_configure, or DRT_ARENA_GB in the environment): what keeps the depth of
+// the ray queues - not their bytes - the same whatever the number of wavelengths a ray carries. A queue entry is 8 LP + 40 bytes (LP:
+// the wavelengths per ray rounded up to a power of two); 16 GiB give 3072 waves ~18 000 rays per queue up to 4 wavelengths, and the
+// same depth at 32 is 66 GiB - a quarter of the device's memory at most. (Round 3: with a flat 16 GiB the first scattering call of the
+// 32-wavelength bench grid was undone three to seven times, the direct light of the N-body grid took 28 s instead of 15.7 s.)
+static size_t default_arena_bytes(const drt_ctx* c)
+{
+    if (const char* e = getenv("DRT_ARENA_GB")) { const double gb = atof(e); if (gb > 0) return (size_t)(gb * 1073741824.0); }
+    const double base = 16.0 * 1073741824.0;
+    double want = base * std::max(1.0, (8.0 * c->LP + 40.0) / 72.0);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) want = std::min(want, std::max(base, 0.25 * (double)total_b));
+    else (void)hipGetLastError();
+    return ((size_t)want + 0xFFFFFull) & ~(size_t)0xFFFFF;
+}
+
 static int ensure_arena(drt_ctx* c)
 {
     if (c->waves <= 0 && c->ray_major) {
@@ -634,7 +651,9 @@ static int ensure_arena(drt_ctx* c)
         c->waves = c->ncu * nb * 4;
     }
     c->waves = (c->waves + 3) / 4 * 4;
+    if (c->d_arena && c->arena_auto && c->arena_lp != c->LP) { (void)hipFree(c->d_arena); c->d_arena = nullptr; }   // sized for other wavelengths
     if (c->d_arena) return DRT_OK;
+    if (c->arena_auto) { c->arena_bytes = default_arena_bytes(c); c->arena_lp = c->LP; }
     HIPCHK(c, hipMalloc((void**)&c->d_arena, c->arena_bytes));
     return DRT_OK;
 }

@@ -1019,10 +1019,10 @@ def test_bench_grid_sample_of_sources_matches_oracle(pkg, tmp_path, monkeypatch)
 def test_a_repeated_stage_is_not_undone_again(pkg):
     """Queue-aware planning (plan_tasks, CNT_QMAX): once a kind of stage has run, its next launches are sized by the longest ray
     queue the last one held - sectors per task and task limit grow only where that queue left room. On TRUST-I tau = 1 with 32
-    wavelengths (21 801 cells) and the default 16 GiB arena the scattering step is repeated three times: whatever the first,
+    wavelengths (21 801 cells) and a 16 GiB arena (4480 rays per queue) the scattering step is repeated three times: whatever the first,
     unmeasured call needs, calls two and three must go through without an undone attempt, and all three trace the same rays."""
     case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=4, wavelengths=list(range(32)), max_sca_iterations=1)
-    g = pkg.DartRayGPU(case)
+    g = pkg.DartRayGPU(case, arena_bytes=16 << 30)
     g.rt_prepare("start")
     g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
     g.rt_prepare("prep_part2")
