@@ -92,7 +92,8 @@ struct drt_ctx {
     int G_want[16] = {0};  // per rt_type: sectors per task suggested by the work per source of the last call of that stage
     bool cheap_sources[16] = {false};  // per rt_type: the last call of that stage saw < 4000 intersections per source (no phase window)
     std::vector<double*> d_bak_scaspe;  // snapshot of the accumulators of a stage, restored when a launch is repeated
-    double *d_bak_u = nullptr, *d_bak_lost = nullptr;
+    double *d_bak_u = nullptr, *d_bak_lost = nullptr, *d_bak_psel = nullptr;
+    size_t bak_psel_n = 0;
     unsigned long long* d_bak_cnt = nullptr;  // lane = ray kernel (rt_wide.hpp) instead of lane = (ray, wavelength)
     std::vector<double> ksca, gsca;
     std::vector<int> npix, npix_hp, kp, ik;
@@ -250,7 +251,7 @@ extern "C" int drt_destroy(drt_ctx* c)
     void* ptrs[] = {c->d_nbr, c->d_cchild, c->d_lvl, c->d_src_cell, c->d_src_list, c->d_cpack, c->d_ccoord, c->d_csize, c->d_dens, c->d_u_fest,
                     c->d_u_final, c->d_lumcell, c->d_p_src_pos, c->d_p_src_lum, c->d_dir_out, c->d_lum_lost, c->d_lum_lost_prev,
                     c->d_i_obs, c->d_tot, c->d_src_cost, c->d_heavy, c->d_deep, c->d_psel_sum, c->d_psel_cnt, c->d_prob, c->d_arena, c->d_counters, c->d_error, c->d_task, c->d_dbg, c->d_spawn, c->d_spawn_counter,
-                    c->d_bak_lost, c->d_bak_cnt};
+                    c->d_bak_lost, c->d_bak_cnt, c->d_bak_psel};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 14; k++) { if (c->d_ring_tab[k]) (void)hipFree(c->d_ring_tab[k]); if (c->d_phi0_tab[k]) (void)hipFree(c->d_phi0_tab[k]); if (c->d_phi1_tab[k]) (void)hipFree(c->d_phi1_tab[k]); }
     if (c->d_dir_out_sc) (void)hipFree(c->d_dir_out_sc);
@@ -1033,6 +1034,7 @@ struct PlanIn {
     bool measured, no_deep;
     double f_last, q_fill; int G_last;
     const double* q48 = nullptr; double cap = 0;   // q48[list[k]], 0 = not known
+    double stage_total = 0;   // > 0: the list is one part of a stage with this sum of costs, and the limit is the stage's, not the part's
 };
 struct PlanOut { std::vector<int> light, deep; std::vector<int2> heavy; double f_used = 0, limit = 0, total = 0; int nbatch_sub = 0; size_t n_heavy_src = 0, n_queue_cut = 0; };
 static void plan_tasks(const PlanIn& in, PlanOut& o)
@@ -1050,7 +1052,7 @@ static void plan_tasks(const PlanIn& in, PlanOut& o)
         if (1.0 / hd > f_max) hd = 1.0 / f_max;
     }
     o.f_used = 1.0 / hd;
-    const double limit = total / (double)in.waves / hd / (double)std::max(1, in.nbatch);
+    const double limit = (in.stage_total > total ? in.stage_total : total) / (double)in.waves / hd / (double)std::max(1, in.nbatch);
     o.limit = limit;
     const bool no_deep = in.no_deep || (in.measured && total / (double)in.waves / (double)std::max(1, in.nbatch) < in.deep_min);
     std::vector<std::pair<double, int>> hv;
@@ -1456,6 +1458,12 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         auto cp = [&](void* bak, void* live, size_t bytes) { return save ? hipMemcpyAsync(bak, live, bytes, hipMemcpyDeviceToDevice, 0) : hipMemcpyAsync(live, bak, bytes, hipMemcpyDeviceToDevice, 0); };
         HIPCHK(c, cp(c->d_bak_u, acc_u, NL * sizeof(double)));
         HIPCHK(c, cp(c->d_bak_cnt, c->d_counters, CNT_N * sizeof(unsigned long long)));
+        if (a.psel_sum && !psrc) {   // a cell stage's sums and counts of ended rays (the point-source stage clears its own entries per attempt)
+            const size_t M = (size_t)c->N + c->nsrc;
+            if (c->bak_psel_n < 2 * M) { if (c->d_bak_psel) (void)hipFree(c->d_bak_psel); c->d_bak_psel = nullptr; HIPCHK(c, hipMalloc((void**)&c->d_bak_psel, 2 * M * sizeof(double))); c->bak_psel_n = 2 * M; }
+            HIPCHK(c, cp(c->d_bak_psel, c->d_psel_sum, M * sizeof(double)));
+            HIPCHK(c, cp(c->d_bak_psel + M, c->d_psel_cnt, M * sizeof(double)));
+        }
         if (direct) {
             HIPCHK(c, cp(c->d_bak_lost, c->d_lum_lost, (size_t)c->L * sizeof(double)));
             for (int il = 0; il < c->L; il++) HIPCHK(c, cp(c->d_bak_scaspe[il], c->d_scaspe[il], (size_t)c->N * c->nstride[il] * sizeof(double)));
@@ -1612,11 +1620,13 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         if (const char* e = getenv("DRT_HEAVY_DIV")) heavy_div = atof(e);
         std::vector<int> light, deep;
         std::vector<int2> heavy;
+        double stage_total = 0;       // sum of the expected costs of all the stage's sources when it runs in parts (else 0)
+        std::vector<int> cur;         // the sources of the launch being prepared: all of the stage's, or one part of them (see the probe below)
         std::vector<double> q_plan;   // a source's measured queue length, else the estimate made after an undone launch, else 0
         auto plan = [&](int Gbase) {
             q_plan.assign((size_t)c->N, 0.0);
             if (c->src_q_h.size() == (size_t)c->N)
-                for (int i : list) q_plan[(size_t)i] = c->src_q_h[(size_t)i] > 0 ? c->src_q_h[(size_t)i] : (c->src_q_est_h.size() == (size_t)c->N ? c->src_q_est_h[(size_t)i] : 0.0);
+                for (int i : cur) q_plan[(size_t)i] = c->src_q_h[(size_t)i] > 0 ? c->src_q_h[(size_t)i] : (c->src_q_est_h.size() == (size_t)c->N ? c->src_q_est_h[(size_t)i] : 0.0);
             double deep_min = 4.0e6;   // shader-clock cycles of wave time per wave (~1.7 ms) below which no source is run as sub-tree tasks:
                                        // config 1 (a 2 ms step): 96 deep sources -> 3.37 ms per step, none -> 2.38, with the limit at 1/8
                                        // 2.06; a 5 ms threshold lost the third scattering iteration of an 8-rank run (36.7 against 15.9 ms)
@@ -1625,16 +1635,53 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             // (4.25 s) instead of overflowing its queues, being undone and repeated at 4 (5.81 s). The queue rule: the first launch,
             // cut at 1/32, fills 52 % of the queues; the second, measured, would be cut at 1/8, overflow and be repeated - at 1/20 it
             // goes through.
-            PlanIn in{list.data(), list.size(), c->src_pred_h.data(), c->waves, Gbase, nbatch, heavy_div, deep_min, c->pred_measured,
+            PlanIn in{cur.data(), cur.size(), c->src_pred_h.data(), c->waves, Gbase, nbatch, heavy_div, deep_min, c->pred_measured,
                       getenv("DRT_NO_DEEP") != nullptr, c->f_last[rt_type & 15], c->q_fill[rt_type & 15], c->G_last[rt_type & 15],
-                      getenv("DRT_NO_SRC_QUEUES") ? nullptr : q_plan.data(), (double)queue_cap(c, max_blocks * 4, Gbase)};
+                      getenv("DRT_NO_SRC_QUEUES") ? nullptr : q_plan.data(), (double)queue_cap(c, max_blocks * 4, Gbase), stage_total};
             PlanOut o;
             plan_tasks(in, o);
             light.swap(o.light); heavy.swap(o.heavy); deep.swap(o.deep);
             nbatch_sub = o.nbatch_sub;
             f_used = o.f_used;
-            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d; %zu cut by their queues, %d rays per queue)\n", rt_type, o.total, o.total / c->waves, o.limit, list.size(), deep.size(), o.n_heavy_src, light.size(), Gbase, o.n_queue_cut, (int)in.cap);
+            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] plan rt %d: total %.3e cycles, per wave %.3e, limit %.3e, sources %zu -> deep %zu heavy %zu light %zu (G %d; %zu cut by their queues, %d rays per queue)\n", rt_type, o.total, o.total / c->waves, o.limit, cur.size(), deep.size(), o.n_heavy_src, light.size(), Gbase, o.n_queue_cut, (int)in.cap);
         };
+        // Queue lengths of the sources nothing was measured of, from the ones that were (fit_queue_prior): the line through
+        // (log luminosity, log queue) times what 99.5 % of the measured sources stay below (at least 2, at most 8).
+        auto estimate_queues = [&]() {
+            if (getenv("DRT_NO_QUEUE_PRIOR")) return;
+            std::vector<double> xl, yq;
+            for (int i : list) if (c->src_q_h[(size_t)i] > 0) { xl.push_back(c->cost_lum_h[(size_t)i]); yq.push_back(c->src_q_h[(size_t)i]); }
+            double fa = 0, fb = 0;
+            if (!fit_queue_prior(xl.data(), yq.data(), xl.size(), fa, fb)) return;
+            std::vector<double> res;
+            for (size_t k = 0; k < xl.size(); k++) if (xl[k] > 0) res.push_back(yq[k] / exp(fa + fb * log(xl[k])));
+            double R = 2.0;
+            if (res.size() >= 64) { const size_t kq = (size_t)(0.995 * (double)(res.size() - 1)); std::nth_element(res.begin(), res.begin() + kq, res.end()); R = std::min(8.0, std::max(2.0, res[kq])); }
+            if (c->src_q_est_h.size() != (size_t)c->N) c->src_q_est_h.assign((size_t)c->N, 0.0);
+            for (int i : list) { const double lum = c->cost_lum_h[(size_t)i]; c->src_q_est_h[(size_t)i] = lum > 0 ? R * exp(fa + fb * log(lum)) : 0.0; }
+            if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] rt %d: queue prior from %zu sources: q48 = %.3g * luminosity^%.2f x %.2f\n", rt_type, xl.size(), exp(fa), fb, R);
+        };
+        // The probe: a stage of which no queue length is known runs an eighth of its sources first (every eighth chunk of 64
+        // consecutive ones: neighbours stay together, the sample covers the model) and plans the others by what these showed -
+        // their own queue lengths give the line and the spread (estimate_queues). An overflow in the probe undoes an eighth of
+        // the stage at most; without it the first overflow of the N-body direct light came 7 s into a 15.7 s stage.
+        std::vector<std::vector<int>> parts;
+        {
+            size_t q_any = 0;
+            if (c->src_q_h.size() == (size_t)c->N) for (int i : list) q_any += c->src_q_h[(size_t)i] > 0;
+            const bool probe = q_any == 0 && list.size() >= 4096 && !use_log && !getenv("DRT_NO_PROBE") && !getenv("DRT_NO_SRC_QUEUES") && c->ray_major;
+            if (probe) {
+                parts.resize(2);
+                for (size_t k = 0; k < list.size(); k++) parts[((k >> 6) & 7) == 0 ? 0 : 1].push_back(list[k]);
+                for (int i : list) stage_total += c->src_pred_h[(size_t)i];   // a task may be as large as in the whole stage's launch: the probe is not cut eight times finer
+            } else parts.push_back(list);
+        }
+        std::vector<double> cost_commit(2 * (size_t)c->N, 0.0);   // src_cost as of the last part that went through
+        if (a.psel_sum) {
+            HIPCHK(c, hipMemsetAsync(c->d_psel_sum, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
+            HIPCHK(c, hipMemsetAsync(c->d_psel_cnt, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
+        }
+        int64_t heavy_done = 0, deep_done = 0;
         bool kept_once = false;
         // The kernel leaves, per source, the longest queue among its whole-sector tasks (second half of src_cost). All tasks of a
         // source take the same number of sectors - the plan's - so the host turns the array into "queue at 48 sectors per task",
@@ -1652,6 +1699,14 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             HIPCHK(c, hipMemcpy(c->d_src_cost + c->N, qh.data(), (size_t)c->N * sizeof(double), hipMemcpyHostToDevice));
             return DRT_OK;
         };
+        for (size_t part = 0; part < parts.size(); part++) {
+        cur = parts[part];
+        kept_once = false;
+        // the probe runs ONE sector per task: 48 times the longest queue of a single sector bounds the source's queue at any number of
+        // sectors, so what the others are planned by errs on the safe side (measured at 8 sectors the spread round the line - up
+        // to x 22 on TRUST-I - let the rest of the N-body direct light overflow twice: 25.5 s; this way not at all: 16.1 s)
+        const int G_stage = Gtry;
+        if (parts.size() > 1 && part == 0) Gtry = 1;
         for (;;) {
             plan(Gtry);
             if (heavy.size() > c->heavy_cap || !c->d_heavy) {
@@ -1667,13 +1722,9 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             if (!heavy.empty()) HIPCHK(c, hipMemcpy(c->d_heavy, heavy.data(), heavy.size() * sizeof(int2), hipMemcpyHostToDevice));
             if (!deep.empty()) HIPCHK(c, hipMemcpy(c->d_deep, deep.data(), deep.size() * sizeof(int), hipMemcpyHostToDevice));
             if (!light.empty()) HIPCHK(c, hipMemcpy(c->d_src_list, light.data(), light.size() * sizeof(int), hipMemcpyHostToDevice));
-            c->cnt.heavy_tasks = (int64_t)heavy.size(); c->cnt.deep_sources = (int64_t)deep.size();
+            c->cnt.heavy_tasks = heavy_done + (int64_t)heavy.size(); c->cnt.deep_sources = deep_done + (int64_t)deep.size();
             if ((rc = copy_state(true))) return rc;
-            HIPCHK(c, hipMemsetAsync(c->d_src_cost, 0, 2 * (size_t)c->N * sizeof(double), 0));
-            if (a.psel_sum) {
-                HIPCHK(c, hipMemsetAsync(c->d_psel_sum, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
-                HIPCHK(c, hipMemsetAsync(c->d_psel_cnt, 0, ((size_t)c->N + c->nsrc) * sizeof(double), 0));
-            }
+            HIPCHK(c, hipMemcpy(c->d_src_cost, cost_commit.data(), cost_commit.size() * sizeof(double), hipMemcpyHostToDevice));   // what an undone attempt left is gone
             HIPCHK(c, hipEventRecord(c->ev0, 0));
             bool ovf = false, fewer = false, ovf_sub = false;
             if (!deep.empty()) {
@@ -1718,23 +1769,35 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 // ... and about the sources that had not run yet: twice what the line through (luminosity, queue) of the measured
                 // ones gives (N-body direct light with the default arena: four undone attempts of ~3 s each, every one stopped by
                 // a source the one before had not reached)
-                std::vector<double> xl, yq;
-                for (int i : list) if (c->src_q_h[(size_t)i] > 0) { xl.push_back(c->cost_lum_h[(size_t)i]); yq.push_back(c->src_q_h[(size_t)i]); }
-                double fa = 0, fb = 0;
-                if (!getenv("DRT_NO_QUEUE_PRIOR") && fit_queue_prior(xl.data(), yq.data(), xl.size(), fa, fb)) {
-                    if (c->src_q_est_h.size() != (size_t)c->N) c->src_q_est_h.assign((size_t)c->N, 0.0);
-                    for (int i : list) { const double lum = c->cost_lum_h[(size_t)i]; c->src_q_est_h[(size_t)i] = lum > 0 ? 2.0 * exp(fa + fb * log(lum)) : 0.0; }
-                    if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] rt %d: queue prior from %zu sources: q48 = %.3g * luminosity^%.2f (x 2)\n", rt_type, xl.size(), exp(fa), fb);
-                }
+                estimate_queues();
             }
             if (learnt && !kept_once) { kept_once = true; continue; }
             if (Gtry > 1) Gtry /= 2;                  // shorter queues first,
             else if (max_blocks > 1) max_blocks = (max_blocks + 1) / 2;  // then fewer waves with deeper ones
             else return fail(c, DRT_E_CAPACITY, "device: %s", trace_error_text(ERR_CAPACITY));
         }
+        // the part went through
+        {
+            double qm = 0.0;
+            if ((rc = scale_queues(Gtry, qm))) return rc;
+            qmax_stage = std::max(qmax_stage, qm);
+            HIPCHK(c, hipMemcpy(cost_commit.data(), c->d_src_cost, cost_commit.size() * sizeof(double), hipMemcpyDeviceToHost));
+            heavy_done += (int64_t)heavy.size(); deep_done += (int64_t)deep.size();
+            if (part + 1 < parts.size()) {
+                // the probe's queue lengths are known now, not at the next call: they make the estimate for the other sources
+                for (int i : cur) if (cost_commit[(size_t)c->N + (size_t)i] > 0) c->src_q_h[(size_t)i] = cost_commit[(size_t)c->N + (size_t)i];
+                estimate_queues();
+                float ms_p = 0;   // its time stays in kernel_ms (ev0 is recorded again for the next part)
+                HIPCHK(c, hipEventRecord(c->ev1, 0));
+                HIPCHK(c, hipEventSynchronize(c->ev1));
+                HIPCHK(c, hipEventElapsedTime(&ms_p, c->ev0, c->ev1));
+                ms_undone += ms_p;
+                Gtry = G_stage;
+            }
+        }
+        }
         if (c->overflow_met) c->G_cell[rt_type & 15] = c->G_cell[rt_type & 15] > 0 ? std::min(c->G_cell[rt_type & 15], Gtry) : Gtry;  // an overflow was met: more sectors than this do not fit this arena
         g_used = Gtry; f_used_stage = f_used;
-        if ((rc = scale_queues(Gtry, qmax_stage))) return rc;
         c->overflow_met = false;
     }
     HIPCHK(c, hipGetLastError());

@@ -1036,3 +1036,30 @@ def test_a_repeated_stage_is_not_undone_again(pkg):
     assert seen[0][:3] == seen[1][:3] == seen[2][:3], seen
     assert seen[1][3] == 0 and seen[2][3] == 0, seen
     g.close()
+
+
+def test_probe_part_changes_the_launches_not_the_result(pkg, monkeypatch):
+    """A stage of which no queue length is known runs an eighth of its sources first, one sector per task, and plans the others by
+    what those showed (rt_loop: the probe). Sums over sources commute: on TRUST-I tau = 1 with 32 wavelengths (21 801 cells, 15 000
+    sources) the first scattering call with the probe and without it (DRT_NO_PROBE) traces the same rays and leaves the same
+    fields; only the launches differ."""
+    case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=4, wavelengths=list(range(32)), max_sca_iterations=1)
+    out = {}
+    for tag in ("probe", "whole"):
+        if tag == "whole":
+            monkeypatch.setenv("DRT_NO_PROBE", "1")
+        g = pkg.DartRayGPU(case)
+        g.rt_prepare("start")
+        g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
+        g.rt_prepare("prep_part2")
+        g.rt_loop("dir_cell"); g.rt_loop("dir_src"); g.rt_mpi("dir_src")
+        assert not g.scatt_prepare()
+        g.reset_counters(); g.rt_loop("scatt")
+        c = g.counters()
+        out[tag] = (c, g.u_final.copy(), g.scaspe(0).copy(), g.scaspe(20).copy(), g.lum_lost.copy())
+        g.close()
+    cp, cw = out["probe"][0], out["whole"][0]
+    assert (cp["intersections"], cp["rays"], cp["deposits"]) == (cw["intersections"], cw["rays"], cw["deposits"])
+    assert cp["launches"] > cw["launches"]
+    for k in (1, 2, 3, 4):
+        assert relmax(out["probe"][k], out["whole"][k]) < 1e-12
