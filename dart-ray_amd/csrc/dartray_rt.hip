@@ -1661,18 +1661,20 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
             for (int i : list) { const double lum = c->cost_lum_h[(size_t)i]; c->src_q_est_h[(size_t)i] = lum > 0 ? R * exp(fa + fb * log(lum)) : 0.0; }
             if (getenv("DRT_TIMING")) fprintf(stderr, "[drt] rt %d: queue prior from %zu sources: q48 = %.3g * luminosity^%.2f x %.2f\n", rt_type, xl.size(), exp(fa), fb, R);
         };
-        // The probe: a stage of which no queue length is known runs an eighth of its sources first (every eighth chunk of 64
+        // The probe: a stage of which no queue length is known runs a sixteenth of its sources first (every sixteenth chunk of 64
         // consecutive ones: neighbours stay together, the sample covers the model) and plans the others by what these showed -
-        // their own queue lengths give the line and the spread (estimate_queues). An overflow in the probe undoes an eighth of
-        // the stage at most; without it the first overflow of the N-body direct light came 7 s into a 15.7 s stage.
+        // their own queue lengths give the line and the spread (estimate_queues). An overflow in the probe undoes a sixteenth of
+        // the stage at most; without it the first overflow of the N-body direct light came 7 s into a 15.7 s stage. Not for
+        // fewer than 8192 sources: with an eighth of the sources and from 4096 on, the first scattering iteration of an 8-rank run
+        // of the bench grid (7475 sources and 0.6 s per rank, no overflow to avoid) took 9 % longer.
         std::vector<std::vector<int>> parts;
         {
             size_t q_any = 0;
             if (c->src_q_h.size() == (size_t)c->N) for (int i : list) q_any += c->src_q_h[(size_t)i] > 0;
-            const bool probe = q_any == 0 && list.size() >= 4096 && !use_log && !getenv("DRT_NO_PROBE") && !getenv("DRT_NO_SRC_QUEUES") && c->ray_major;
+            const bool probe = q_any == 0 && list.size() >= 8192 && !use_log && !getenv("DRT_NO_PROBE") && !getenv("DRT_NO_SRC_QUEUES") && c->ray_major;
             if (probe) {
                 parts.resize(2);
-                for (size_t k = 0; k < list.size(); k++) parts[((k >> 6) & 7) == 0 ? 0 : 1].push_back(list[k]);
+                for (size_t k = 0; k < list.size(); k++) parts[((k >> 6) & 15) == 0 ? 0 : 1].push_back(list[k]);
                 for (int i : list) stage_total += c->src_pred_h[(size_t)i];   // a task may be as large as in the whole stage's launch: the probe is not cut eight times finer
             } else parts.push_back(list);
         }

@@ -1039,7 +1039,7 @@ def test_a_repeated_stage_is_not_undone_again(pkg):
 
 
 def test_probe_part_changes_the_launches_not_the_result(pkg, monkeypatch):
-    """A stage of which no queue length is known runs an eighth of its sources first, one sector per task, and plans the others by
+    """A stage of which no queue length is known (8192 sources or more) runs a sixteenth of them first, one sector per task, and plans the others by
     what those showed (rt_loop: the probe). Sums over sources commute: on TRUST-I tau = 1 with 32 wavelengths (21 801 cells, 15 000
     sources) the first scattering call with the probe and without it (DRT_NO_PROBE) traces the same rays and leaves the same
     fields; only the launches differ."""
