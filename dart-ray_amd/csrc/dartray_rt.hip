@@ -605,7 +605,7 @@ template <int LP> static int wide_blocks_per_cu(drt_ctx* c) { return std::min(wi
 // The queue arena of a context that was not given one (drt_configure, or DRT_ARENA_GB in the environment): what keeps the depth of
 // the ray queues - not their bytes - the same whatever the number of wavelengths a ray carries. A queue entry is 8 LP + 40 bytes (LP:
 // the wavelengths per ray rounded up to a power of two); 16 GiB give 3072 waves ~18 000 rays per queue up to 4 wavelengths, and the
-// same depth at 32 is 66 GiB - a quarter of the device's memory at most. (Round 3: with a flat 16 GiB the first scattering call of the
+// same depth at 32 is 66 GiB - a quarter of the device's memory and 60 % of what is free at most. (Round 3: with a flat 16 GiB the first scattering call of the
 // 32-wavelength bench grid was undone three to seven times, the direct light of the N-body grid took 28 s instead of 15.7 s.)
 static size_t default_arena_bytes(const drt_ctx* c)
 {
@@ -613,8 +613,10 @@ static size_t default_arena_bytes(const drt_ctx* c)
     const double base = 16.0 * 1073741824.0;
     double want = base * std::max(1.0, (8.0 * c->LP + 40.0) / 72.0);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) want = std::min(want, std::max(base, 0.25 * (double)total_b));
-    else (void)hipGetLastError();
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+        want = std::min(want, std::max(base, 0.25 * (double)total_b));
+        want = std::min(want, std::max(4.0 * 1073741824.0, 0.6 * (double)free_b));   // several contexts on one device, other tenants: what is left decides
+    } else (void)hipGetLastError();
     return ((size_t)want + 0xFFFFFull) & ~(size_t)0xFFFFF;
 }
 

@@ -121,7 +121,7 @@ const char *drt_last_error(const drt_ctx *ctx);
 /* arena_bytes: device memory for the per-wave ray queues; waves: persistent wavefronts (0 = as many as the chip keeps resident).
  * arena_bytes 0 = leave as it is; a context that was never given one sizes it when it is first needed: DRT_ARENA_GB from the
  * environment if set, else 16 GiB x max(1, (8 LP + 40) / 72) with LP = the wavelengths per ray rounded up to a power of two - the
- * queue DEPTH of 16 GiB at four wavelengths, e.g. 66 GiB at 32 - and at most a quarter of the device's memory. Queues that still
+ * queue DEPTH of 16 GiB at four wavelengths, e.g. 66 GiB at 32 - and at most a quarter of the device's memory and 60 % of what is free. Queues that still
  * overflow are handled (the launch is undone and repeated with finer tasks); a larger arena saves those repeats. */
 int drt_configure(drt_ctx *ctx, size_t arena_bytes, int waves);
 
