@@ -338,6 +338,15 @@ contains
     call gpu_check(drt_comm_init(gpu_ctx, int(np_mpi, c_int32_t), int(id_mpi, c_int32_t), id), 'drt_comm_init')
   end subroutine gpu_comm_init
 
+  !> Memory for the ray queues in GiB and the number of persistent wavefronts (drt_configure; 0 = leave as it is). Not needed for a
+  !> run: a context that is never configured sizes its queues by itself (DRT_ARENA_GB in the environment, else by the number of
+  !> wavelengths and the device's memory, include/dartray_rt.h).
+  subroutine gpu_configure(arena_gib, waves)
+    real(c_double), intent(in) :: arena_gib
+    integer, intent(in) :: waves
+    call gpu_check(drt_configure(gpu_ctx, int(arena_gib * 1073741824.0_c_double, c_size_t), int(waves, c_int)), 'drt_configure')
+  end subroutine gpu_configure
+
   !> The library's RCCL path on one rank (drt_comm_selftest): stops with the library's message when RCCL cannot be used here.
   subroutine gpu_comm_selftest()
     call gpu_check(drt_comm_selftest(gpu_ctx), 'drt_comm_selftest')
