@@ -1709,7 +1709,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
         // the probe runs ONE sector per task: 48 times the longest queue of a single sector bounds the source's queue at any number of
         // sectors, so what the others are planned by errs on the safe side (measured at 8 sectors the spread round the line - up
         // to x 22 on TRUST-I - let the rest of the N-body direct light overflow twice: 25.5 s; this way not at all: 16.1 s)
-        const int G_stage = Gtry;
+        const int G_stage = Gtry, blocks_stage = max_blocks;
         if (parts.size() > 1 && part == 0) Gtry = 1;
         for (;;) {
             plan(Gtry);
@@ -1796,7 +1796,7 @@ extern "C" int drt_rt_loop(drt_ctx* c, int32_t rt_type)
                 HIPCHK(c, hipEventSynchronize(c->ev1));
                 HIPCHK(c, hipEventElapsedTime(&ms_p, c->ev0, c->ev1));
                 ms_undone += ms_p;
-                Gtry = G_stage;
+                Gtry = G_stage; max_blocks = blocks_stage;   // what the probe had to give up (sectors it never had; waves, if its queues overflowed twice) is the probe's affair
             }
         }
         }
