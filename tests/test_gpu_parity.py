@@ -1049,6 +1049,7 @@ def test_probe_part_changes_the_launches_not_the_result(pkg, monkeypatch):
         if tag == "whole":
             monkeypatch.setenv("DRT_NO_PROBE", "1")
         g = pkg.DartRayGPU(case)
+        g.set_psel_av(True)   # the average path of every source's rays: sums that must survive the stage running in parts
         g.rt_prepare("start")
         g.rt_loop("precalc_cell"); g.rt_loop("precalc_src"); g.rt_mpi("precalc_src")
         g.rt_prepare("prep_part2")
@@ -1056,10 +1057,12 @@ def test_probe_part_changes_the_launches_not_the_result(pkg, monkeypatch):
         assert not g.scatt_prepare()
         g.reset_counters(); g.rt_loop("scatt")
         c = g.counters()
-        out[tag] = (c, g.u_final.copy(), g.scaspe(0).copy(), g.scaspe(20).copy(), g.lum_lost.copy())
+        psel = g.get_array("psel_av")
+        assert (psel[:g.N] > 0).sum() == c["sources"]
+        out[tag] = (c, g.u_final.copy(), g.scaspe(0).copy(), g.scaspe(20).copy(), g.lum_lost.copy(), psel)
         g.close()
     cp, cw = out["probe"][0], out["whole"][0]
     assert (cp["intersections"], cp["rays"], cp["deposits"]) == (cw["intersections"], cw["rays"], cw["deposits"])
     assert cp["launches"] > cw["launches"]
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 5):
         assert relmax(out["probe"][k], out["whole"][k]) < 1e-12
