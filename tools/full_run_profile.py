@@ -13,7 +13,7 @@ max_it = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 wl = list(range(32)) if nl == 32 else [11]
 case = pkg.grids.trusti_case(tau_z=1.0, max_lvl=max_lvl, wavelengths=wl, max_sca_iterations=max_it)
 t00 = time.time()
-g = pkg.DartRayGPU(case, arena_bytes=200 << 30)
+g = pkg.DartRayGPU(case, arena_bytes=int(os.environ.get("ARENA_GB", "200")) << 30)   # ARENA_GB=0: the library's own choice
 rows = []
 
 
